@@ -1,0 +1,252 @@
+/*
+ * nsr.h -- C ABI of libnsr_hip.so, the MI355X (gfx950) volume-rendering hot path.
+ *
+ * Drop-in boundary for the two pybind11 extension modules of hkust-vgd/nerfstyle
+ *   _raymarching  (raymarching/src/bindings.cpp:5-21, signatures raymarching/src/raymarching.h:6-38)
+ *   _gridencoder  (gridencoder/src/bindings.cpp:5-8,  signatures gridencoder/src/gridencoder.h:12-14)
+ * and for the third native surface the reference reaches through tinycudann
+ *   tcnn.Network  (networks/style_nerf.py:44-98)
+ * plus fused entry points that have no reference counterpart (the reference launches
+ * march / encode x2 / MLP x4 / exp / cat / composite separately).
+ *
+ * Contract (same as the reference's):
+ *   - plain C, raw DEVICE pointers + explicit sizes + a HIP stream; no torch types;
+ *   - the caller allocates every output and every workspace; the library never allocates,
+ *     frees or retains device memory and keeps no state (re-entrant, thread-safe);
+ *   - no host synchronisation, no host reads of device data: every call is legal inside
+ *     hipGraph stream capture;
+ *   - returns an int status (0 = ok, <0 = error) and never throws; the reference returns void
+ *     and raises c10::Error / std::runtime_error (gridencoder.cu:369,387,414,433,440-487) --
+ *     the Python wrappers turn a negative status into RuntimeError.
+ *   - pointer arguments marked "host" are read on the host at call time (small tables).
+ *
+ * Element-type codes (nsr_dtype): the reference dispatches on at::ScalarType
+ * (AT_DISPATCH_FLOATING_TYPES_AND_HALF); this ABI passes a code.
+ */
+#ifndef NSR_H_
+#define NSR_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void *nsr_stream_t; /* a hipStream_t */
+
+enum nsr_status {
+    NSR_OK = 0,
+    NSR_ERR_INVALID_ARG = -1, /* null pointer, bad size, bad enum */
+    NSR_ERR_UNSUPPORTED = -2, /* configuration outside what the kernels are built for */
+    NSR_ERR_LAUNCH = -3       /* hipGetLastError() after the launch was not hipSuccess */
+};
+
+enum nsr_dtype { NSR_F32 = 0, NSR_F16 = 1, NSR_BF16 = 2 };
+enum nsr_activation { NSR_ACT_NONE = 0, NSR_ACT_SIGMOID = 1 };
+
+const char *nsr_status_string(int status);
+/* ABI version; bumped on any signature change. */
+int nsr_abi_version(void);
+/* "gfx950" -- the only code object in the library. */
+const char *nsr_target_arch(void);
+
+/* ------------------------------------------------------------------------------------------
+ * _raymarching replacements
+ * ------------------------------------------------------------------------------------------ */
+
+/* replaces near_far_from_aabb (raymarching.h:6, raymarching.cu:190-255).
+ * rays_o, rays_d [N,3] f32; aabb [6] f32 (device); nears, fars [N] f32. */
+int nsr_near_far_from_aabb(const float *rays_o, const float *rays_d, const float *aabb, uint32_t N,
+                           float min_near, float *nears, float *fars, nsr_stream_t stream);
+
+/* replaces morton3D (raymarching.h:8, raymarching.cu:313-331). coords [N,3] i32 -> indices [N] i32 */
+int nsr_morton3d(const int32_t *coords, uint32_t N, int32_t *indices, nsr_stream_t stream);
+
+/* replaces morton3D_invert (raymarching.h:9, raymarching.cu:336-359). */
+int nsr_morton3d_invert(const int32_t *indices, uint32_t N, int32_t *coords, nsr_stream_t stream);
+
+/* replaces packbits (raymarching.h:10, raymarching.cu:366-399).
+ * grid f32 [N*8]; bitfield u8 [N]; bit i of byte n = grid[8n+i] > density_thresh. */
+int nsr_packbits(const float *grid, uint32_t N, float density_thresh, uint8_t *bitfield,
+                 nsr_stream_t stream);
+
+/* replaces march_rays_train (raymarching.h:12, raymarching.cu:410-599).
+ *
+ * Same outputs as the reference kernel, with one strengthening: sample offsets come from an
+ * exclusive scan over ray index instead of atomicAdd arrival order (raymarching.cu:506-507),
+ * so `rays` is deterministic: row n = (n, offset_n, count_n).  That is one of the orders the
+ * reference can produce.  counter[0] += total samples, counter[1] += N (the reference's
+ * atomics), so a non-zero incoming counter offsets the allocation exactly as there.
+ *
+ * xyzs [M,3], deltas [M,4] f32 (slots 2,3 only written when is_ndc), dirs [M,3] or NULL (the
+ * model on this path is built with use_dir=False and never reads it), rays [N,3] i32,
+ * counter [2] i32, noises [N] f32 or NULL (= zeros: perturb is force-disabled,
+ * raymarching.py:247), z_hats [N] or NULL when !is_ndc.
+ * Rays with offset+count >= M are dropped like the reference does (raymarching.cu:517).
+ * workspace: nsr_march_rays_train_workspace_bytes(N) bytes of device scratch. */
+uint64_t nsr_march_rays_train_workspace_bytes(uint32_t N);
+int nsr_march_rays_train(const float *rays_o, const float *rays_d, const float *z_hats,
+                         const uint8_t *grid, float bound, float dt_gamma, uint32_t max_steps,
+                         int is_ndc, uint32_t N, uint32_t C, uint32_t H, uint32_t M,
+                         const float *nears, const float *fars, float *xyzs, float *dirs,
+                         float *deltas, int32_t *rays, int32_t *counter, const float *noises,
+                         void *workspace, nsr_stream_t stream);
+
+/* replaces composite_rays_train_forward (raymarching.h:14, raymarching.cu:806-890).
+ * sigmas [M], rgbs [M,C], deltas [M,4], rays [N,3] -> weights_sum [N], depth [N], image [N,C].
+ * M is the sample-buffer size the march used for its "offset+count >= M" drop test
+ * (raymarching.cu:517,830): pass the same value.  C <= 16. */
+int nsr_composite_rays_train_forward(const float *sigmas, const float *rgbs, const float *deltas,
+                                     const int32_t *rays, uint32_t M, uint32_t N,
+                                     uint32_t C, float T_thresh, int is_ndc, float *weights_sum,
+                                     float *depth, float *image, nsr_stream_t stream);
+
+/* replaces composite_rays_train_backward (raymarching.h:15, raymarching.cu:904-997).
+ * The reference needs grad_sigmas, grad_rgbs pre-zeroed and an [N,C] scratch rgbs_buf
+ * (raymarching.py:339-341); here the running colour sum lives in registers, rgbs_buf is gone,
+ * and entries of grad_sigmas / grad_rgbs the reference leaves at zero are written as zero
+ * only inside live rays -- callers still pass zero-filled buffers for dropped rays and padding. */
+int nsr_composite_rays_train_backward(const float *grad_weights_sum, const float *grad_image,
+                                      const float *sigmas, const float *rgbs, const float *deltas,
+                                      const int32_t *rays, int is_ndc, const float *weights_sum,
+                                      const float *image, uint32_t M, uint32_t N,
+                                      uint32_t C, float T_thresh, float *grad_sigmas, float *grad_rgbs,
+                                      nsr_stream_t stream);
+
+/* replaces march_rays (raymarching.h:17, raymarching.cu:1004-1130), inference. */
+int nsr_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t *rays_alive, const float *rays_t,
+                   const float *rays_o, const float *rays_d, const float *z_hats, float bound,
+                   float dt_gamma, uint32_t max_steps, int is_ndc, uint32_t C, uint32_t H,
+                   const uint8_t *grid, const float *nears, const float *fars, float *xyzs, float *dirs,
+                   float *deltas, const float *noises, nsr_stream_t stream);
+
+/* replaces composite_rays (raymarching.h:18, raymarching.cu:1133-1240), inference, in place. */
+int nsr_composite_rays(uint32_t n_alive, uint32_t n_step, float T_thresh, int32_t *rays_alive,
+                       float *rays_t, const float *sigmas, const float *rgbs, const float *deltas,
+                       uint32_t C, int is_ndc, float *weights_sum, float *depth, float *image,
+                       nsr_stream_t stream);
+
+/* Alive-ray compaction on the device (replaces the boolean-mask `rays_alive[rays_alive >= 0]`
+ * of renderer.py:284, which is a host sync): stable, ballot/scan based.
+ * out [n_alive] i32, n_out [1] i32 (device).  workspace: nsr_compact_alive_workspace_bytes(n). */
+uint64_t nsr_compact_alive_workspace_bytes(uint32_t n_alive);
+int nsr_compact_alive(const int32_t *rays_alive, uint32_t n_alive, int32_t *out, int32_t *n_out,
+                      void *workspace, nsr_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * _gridencoder replacements
+ * ------------------------------------------------------------------------------------------ */
+
+/* gridencoder.cu:137 evaluated once on the host: resolution[l] = floor(exp2f(l*S)*H), fp32.
+ * The kernels take this table instead of re-evaluating exp2f per thread. res_out host [L]. */
+int nsr_grid_resolutions(uint32_t L, float S, uint32_t H, uint32_t *res_out);
+
+/* replaces grid_encode_forward (gridencoder.h:12, gridencoder.cu:83-235,439-461), D = 3.
+ * inputs [B,3] f32 in [0,1]; embeddings [rows,C] of emb_dtype (NSR_F32|NSR_F16);
+ * offsets HOST [L+1] i32 (the reference passes a device tensor; it is 17 ints);
+ * outputs of emb_dtype: layout [L,B,C] when out_blc == 0 (the reference kernel's) or
+ * [B,L*C] when out_blc != 0 (what grid.py:58 returns after its permute+reshape copy).
+ * calc_grad_inputs is not supported (never true on this path) -> NSR_ERR_UNSUPPORTED.
+ * C in {1,2,4,8} like the reference; L <= 32. */
+int nsr_grid_encode_forward(const float *inputs, const void *embeddings, int emb_dtype,
+                            const int32_t *offsets, void *outputs, uint32_t B, uint32_t D, uint32_t C,
+                            uint32_t L, float S, uint32_t H, int calc_grad_inputs, uint32_t gridtype,
+                            int align_corners, uint32_t style, int out_blc, nsr_stream_t stream);
+
+/* replaces grid_encode_backward (gridencoder.h:13, gridencoder.cu:238-328,464-494).
+ * grad of grad_dtype in the layout selected by grad_blc; grad_embeddings [rows,C] f32 ALWAYS
+ * (fp32 atomics; the reference accumulates in half under AMP) and arrives zeroed or holding a
+ * running sum (the kernel accumulates). */
+int nsr_grid_encode_backward(const void *grad, int grad_dtype, const float *inputs,
+                             const int32_t *offsets, float *grad_embeddings, uint32_t B, uint32_t D,
+                             uint32_t C, uint32_t L, float S, uint32_t H, uint32_t gridtype,
+                             int align_corners, uint32_t style, int grad_blc, nsr_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * tcnn.Network replacement: bias-free fully fused MLP on MFMA
+ * ------------------------------------------------------------------------------------------
+ * params: fp32 master weights, flat, row-major [out,in] per layer, layers concatenated, the
+ * last layer's rows padded to a multiple of 16 (nsr_mlp_param_count).  Hidden width 64, ReLU.
+ * Compute contract: inputs, weights and hidden activations rounded to compute_dtype
+ * (NSR_F16 | NSR_BF16), products accumulated in fp32 by v_mfma_f32_16x16x32_{f16,bf16}.
+ * x [M,n_in] f32; y [M,n_out] f32 (after out_act).  n_in in {16,32,64}; n_out <= 16;
+ * n_hidden_layers in {1,2}; n_neurons == 64. */
+uint32_t nsr_mlp_param_count(uint32_t n_in, uint32_t n_out, uint32_t n_neurons, uint32_t n_hidden_layers);
+int nsr_mlp_forward(const float *x, const float *params, uint32_t M, uint32_t n_in, uint32_t n_out,
+                    uint32_t n_neurons, uint32_t n_hidden_layers, int out_act, int compute_dtype,
+                    float *y, nsr_stream_t stream);
+/* dy [M,n_out] f32 = dL/dy (post-activation); y [M,n_out] the forward output (for sigmoid').
+ * dx [M,n_in] f32 or NULL; dparams [count] f32 is ACCUMULATED into (fp32 atomics, one add per
+ * workgroup per weight).  Activations are recomputed, nothing is saved by the forward. */
+int nsr_mlp_backward(const float *x, const float *params, const float *y, const float *dy, uint32_t M,
+                     uint32_t n_in, uint32_t n_out, uint32_t n_neurons, uint32_t n_hidden_layers,
+                     int out_act, int compute_dtype, float *dx, float *dparams, nsr_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Fused field: BBox.normalize -> 2x hash encode -> 4 MLPs -> trunc_exp / sigmoid / cat
+ * (networks/style_nerf.py:120-142, use_dir = False) in ONE launch per direction.
+ * ------------------------------------------------------------------------------------------
+ * Data layout (MI355X-first): the two hash tables are stored INTERLEAVED,
+ *   tables[row][enc][feat], enc 0 = x_density_embedder, enc 1 = x_color_embedder, feat < 2,
+ * so that one 16-byte (f32) / 8-byte (f16) load or one 64-byte atomic request serves both
+ * encoders (same positions, same hash => same row).  grad_tables has the same layout, f32.
+ * mlp_params: the four flat fp32 parameter vectors concatenated in the order
+ *   density (32->64->1), color1 (32->64->16), color2 (16->64->64->3), class (32->64->nc);
+ * grad_mlp likewise (accumulated into).
+ */
+typedef struct nsr_field_desc {
+    uint32_t L;                /* levels (16) */
+    uint32_t H;                /* base resolution (16) */
+    float S;                   /* log2(per_level_scale), fp32 (grid.py:36) */
+    uint32_t num_classes;      /* nc <= 13; output channels C_ch = 3 + nc */
+    int table_dtype;           /* NSR_F32 | NSR_F16: element type of `tables` */
+    int compute_dtype;         /* NSR_F16 | NSR_BF16 for the MFMA chain */
+    float bbox_min[3];         /* BBox.normalize: x_hat = (x - min) / size (common.py:276-288) */
+    float bbox_size[3];
+    float density_scale;       /* renderer.py:225, folded into sigma */
+    const int32_t *offsets;    /* HOST [L+1], rows (grid.py:129-140) */
+} nsr_field_desc;
+
+/* xyzs [M,3] f32 world positions.  sigmas [M] f32 = exp(logit) * density_scale;
+ * rgbs [M, 3+nc] f32 = cat(sigmoid(rgb), classes) or NULL for the sigma-only branch
+ * (style_nerf.py:125-126).  m_dev: optional device int32 sample count (<= M) -- tiles past it
+ * are skipped, so callers can size M as a capacity and never read the count on the host. */
+int nsr_field_forward(const nsr_field_desc *desc, const void *tables, const float *mlp_params,
+                      const float *xyzs, uint32_t M, const int32_t *m_dev, float *sigmas, float *rgbs,
+                      nsr_stream_t stream);
+
+/* grad_sigmas [M], grad_rgbs [M,3+nc] f32.  Recomputes the forward (nothing saved), then
+ * back-propagates: trunc_exp' = exp(clamp(logit,-15,15)) (tcnn_nerf.py:62-66), sigmoid', ReLU
+ * masks, MLP dgrad on MFMA, wgrad on MFMA (accumulated into grad_mlp), and scatters the
+ * encoder gradient into grad_tables with fp32 atomics (both encoders per request).
+ * train_density_table / train_color_table: 0 skips that encoder's scatter (stylisation
+ * optimises x_color_embedder only, trainers/style.py:25). */
+int nsr_field_backward(const nsr_field_desc *desc, const void *tables, const float *mlp_params,
+                       const float *xyzs, uint32_t M, const int32_t *m_dev, const float *grad_sigmas,
+                       const float *grad_rgbs, float *grad_tables, float *grad_mlp,
+                       int train_density_table, int train_color_table, nsr_stream_t stream);
+
+/* fp32 master tables -> f16 gather copy (the reference's `embeddings.to(torch.half)` under
+ * autocast, grid.py:42-43).  n = number of scalars. */
+int nsr_cast_f32_to_f16(const float *src, void *dst, uint64_t n, nsr_stream_t stream);
+
+/* Fused Adam (+ optional EMA shadow) over a flat fp32 arena, one pass, grads zeroed on the way
+ * out (replaces torch.optim.Adam + zero_grad + torch_ema, trainers/base.py:216-229,420-426).
+ * grad_scale_inv multiplies the gradient first (GradScaler unscale). step >= 1.
+ * half_copy (f16, may be NULL) receives the updated parameters rounded to half. */
+int nsr_adam_step(float *params, float *grads, float *exp_avg, float *exp_avg_sq, float *ema,
+                  void *half_copy, uint64_t n, float lr, float beta1, float beta2, float eps,
+                  float grad_scale_inv, float ema_decay, uint32_t step, nsr_stream_t stream);
+
+/* Ray generation on the device (nerf_lib.py:69-142 + common.py:139-147): pixel centres
+ * (x + 0.5), camera-frame direction ((i-cx)/fx, (j-cy)/fy, 1) * flip, R * d, normalise.
+ * pose [4,4] f32 row-major (device).  pix [N] i32 1-D pixel ids (row-major, y * w + x) or NULL
+ * for all w*h pixels in order (then N == w*h).  flip bits as camera_flip (nerf_lib.py:121). */
+int nsr_generate_rays(const float *pose, uint32_t w, uint32_t h, float fx, float fy, float cx,
+                      float cy, int camera_flip, const int32_t *pix, uint32_t N, float *rays_o,
+                      float *rays_d, nsr_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NSR_H_ */

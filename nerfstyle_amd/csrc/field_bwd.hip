@@ -1,0 +1,347 @@
+// Fused field backward for gfx950.  One launch does what the reference does with composite's
+// saved tensors + 4 tcnn backward launches + 2 grid backward launches (+ two zeros_like fills):
+//
+//   recompute encode + forward chain (nothing was saved by the forward: no [M,.] activations in
+//   HBM) -> trunc_exp' / sigmoid' / ReLU masks -> dgrad chain on MFMA (W^T as the A operand,
+//   samples stay on lanes) -> wgrad on MFMA -> table scatter with fp32 atomics.
+//
+// wgrad needs the sample index on the MFMA k axis, i.e. every activation / gradient block
+// transposed.  That is done in registers with one 16x16x16 MFMA against the identity per block
+// (exact), not through LDS.  The 60 weight-gradient tiles (15360 fp32) are accumulated in LDS
+// (ds_add_f32) across all the tiles a workgroup processes and flushed with one global atomic
+// per weight per workgroup at the end.
+//
+// Lane (s = lane&15, g = lane>>4) owns levels {2g, 2g+1, 8+2g, 9+2g} of sample s in both
+// directions, so dX arrives from the MFMA on the lane that scatters it.
+#include "field_common.h"
+
+// ---- backward LDS image (units: shorts) ------------------------------------------------------
+constexpr int BW_R3T = 0;        // r3^T  [64 x 16]  4 frag16
+constexpr int BW_R2T = 1024;     // r2^T  [64 x 64]  8 frag32
+constexpr int BW_R1T = 5120;     // r1^T  [16 x 64]  2 frag32
+constexpr int BW_C1BT = 6144;    // c1b^T [64 x 16]  4 frag16
+constexpr int BW_C1AT = 7168;    // c1a^T [32 x 64]  4 frag32
+constexpr int BW_K2T = 9216;     // k2^T  [64 x 16]  4 frag16 (k index = class row + 3)
+constexpr int BW_K1T = 10240;    // k1^T  [32 x 64]  4 frag32
+constexpr int BW_D2T = 12288;    // d2^T  [64 x 16]  4 frag16
+constexpr int BW_D1T = 13312;    // d1^T  [32 x 64]  4 frag32
+constexpr int BW_TOTAL = 15360;
+
+constexpr int BWD_THREADS = 512;
+constexpr size_t BWD_LDS_BYTES = (size_t)FW_TOTAL * 2 + (size_t)BW_TOTAL * 2 + (size_t)P_TOTAL * 4 + 16 * sizeof(NsrLevel);
+
+struct FieldBwdArgs {
+    FieldArgs f;
+    const float *grad_sigmas;
+    const float *grad_rgbs;
+    float *grad_tables;
+    float *grad_mlp;
+    int train_density, train_color;
+    uint32_t nc;
+};
+
+template <int CD>
+__device__ __forceinline__ void field_build_bw(short *lds, const float *__restrict__ p) {
+    mm_build_frags<CD>(lds + BW_R3T, p + P_R3, 16, 64, 4, 16, true, 0, false);
+    mm_build_frags<CD>(lds + BW_R2T, p + P_R2, 64, 64, 4, 64, true, 0, true);
+    mm_build_frags<CD>(lds + BW_R1T, p + P_R1, 64, 16, 1, 64, true, 0, true);
+    mm_build_frags<CD>(lds + BW_C1BT, p + P_C1B, 16, 64, 4, 16, true, 0, false);
+    mm_build_frags<CD>(lds + BW_C1AT, p + P_C1A, 64, 32, 2, 64, true, 0, true);
+    mm_build_frags<CD>(lds + BW_K2T, p + P_K2, 16, 64, 4, 16, true, CLASS_ROW_SHIFT, false);
+    mm_build_frags<CD>(lds + BW_K1T, p + P_K1, 64, 32, 2, 64, true, 0, true);
+    mm_build_frags<CD>(lds + BW_D2T, p + P_D2, 16, 64, 4, 16, true, 0, false);
+    mm_build_frags<CD>(lds + BW_D1T, p + P_D1, 64, 32, 2, 64, true, 0, true);
+}
+
+// wgrad of one layer over this wave's 16 samples:
+//   dW[o][i] += sum_s G[o][s] * A[i][s]
+// Gt / At are the transposed blocks (lane = feature, elements = samples 4g+e).  Result tile
+// (ot,it): lane (i = lane&15, g) element e = dW[16ot + 4g + e][16it + i].  Rows are shifted by
+// row_shift and clipped to [row_lo, row_hi) (rows outside can only hold zeros).
+template <int CD, int NG, int NA>
+__device__ __forceinline__ void field_wgrad(float *lds_w, int in_p, int row_shift, int row_lo, int row_hi, const s4v (&Gt)[NG],
+                                            const s4v (&At)[NA], int lane) {
+    const int i = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int ot = 0; ot < NG; ot++) {
+#pragma unroll
+        for (int it = 0; it < NA; it++) {
+            f4v z = {0.f, 0.f, 0.f, 0.f};
+            const f4v d = MM<CD>::k16(Gt[ot], At[it], z);
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const int row = 16 * ot + 4 * g + e - row_shift;
+                if (row >= row_lo && row < row_hi) atomicAdd(&lds_w[row * in_p + 16 * it + i], d[e]);
+            }
+        }
+    }
+}
+
+template <int CD>
+__device__ __forceinline__ void field_tr2(const s8v (&x)[1], s4v ident, s4v (&out)[2]) {
+    out[0] = mm_transpose16<CD>(mm_lo(x[0]), ident);
+    out[1] = mm_transpose16<CD>(mm_hi(x[0]), ident);
+}
+template <int CD>
+__device__ __forceinline__ void field_tr4(const s8v (&x)[2], s4v ident, s4v (&out)[4]) {
+    out[0] = mm_transpose16<CD>(mm_lo(x[0]), ident);
+    out[1] = mm_transpose16<CD>(mm_hi(x[0]), ident);
+    out[2] = mm_transpose16<CD>(mm_lo(x[1]), ident);
+    out[3] = mm_transpose16<CD>(mm_hi(x[1]), ident);
+}
+
+// 4 gradient tiles -> masked by the forward activation -> two K=32 B fragments
+template <int CD>
+__device__ __forceinline__ void field_mask_pack(const f4v (&gacc)[4], const s8v (&act)[2], s8v (&out)[2]) {
+    out[0] = mm_cat(mm_round4<CD, false>(mm_relu_mask(gacc[0], mm_lo(act[0]))),
+                    mm_round4<CD, false>(mm_relu_mask(gacc[1], mm_hi(act[0]))));
+    out[1] = mm_cat(mm_round4<CD, false>(mm_relu_mask(gacc[2], mm_lo(act[1]))),
+                    mm_round4<CD, false>(mm_relu_mask(gacc[3], mm_hi(act[1]))));
+}
+
+// Scatter one level's gradient (both encoders) into the interleaved fp32 gradient table.
+__device__ __forceinline__ void field_scatter_level(const NsrLevel &lv, float *__restrict__ gt, float u0, float u1, float u2,
+                                                    float gd0, float gd1, float gc0, float gc1, bool td, bool tc) {
+    float f[3];
+    uint32_t c[3];
+    nsr_grid_locate(u0, lv.resolution, 1, f[0], c[0]);
+    nsr_grid_locate(u1, lv.resolution, 1, f[1], c[1]);
+    nsr_grid_locate(u2, lv.resolution, 1, f[2], c[2]);
+#pragma unroll
+    for (uint32_t idx = 0; idx < 8; idx++) {
+        float w = 1;
+        uint32_t p[3];
+#pragma unroll
+        for (uint32_t d = 0; d < 3; d++) {
+            if ((idx & (1u << d)) == 0) { w *= 1 - f[d]; p[d] = c[d]; }
+            else { w *= f[d]; p[d] = c[d] + 1; }
+        }
+        float *row = gt + (size_t)(lv.offset + nsr_grid_row(lv, p[0], p[1], p[2], 0u)) * 4;
+        if (td) { atomicAdd(row + 0, w * gd0); atomicAdd(row + 1, w * gd1); }
+        if (tc) { atomicAdd(row + 2, w * gc0); atomicAdd(row + 3, w * gc1); }
+    }
+}
+
+template <typename TT, int CD>
+__global__ void __launch_bounds__(BWD_THREADS)
+k_field_bwd(FieldBwdArgs b) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    short *wl = reinterpret_cast<short *>(smem);
+    short *wt = wl + FW_TOTAL;
+    float *wg = reinterpret_cast<float *>(smem + (size_t)(FW_TOTAL + BW_TOTAL) * 2);
+    NsrLevel *lds_lv = reinterpret_cast<NsrLevel *>(smem + (size_t)(FW_TOTAL + BW_TOTAL) * 2 + (size_t)P_TOTAL * 4);
+    const FieldArgs &a = b.f;
+    field_build_fw<CD, false>(wl, a.params);
+    field_build_bw<CD>(wt, a.params);
+    for (int i = threadIdx.x; i < P_TOTAL; i += BWD_THREADS) wg[i] = 0.0f;
+    if (threadIdx.x < 16) lds_lv[threadIdx.x] = a.lv[threadIdx.x];
+    __syncthreads();
+
+    const uint32_t Mc = a.m_dev ? min((uint32_t)max(a.m_dev[0], 0), a.M) : a.M;
+    const uint32_t ntiles = (Mc + 15) / 16;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int s = lane & 15, g = lane >> 4;
+    const TT *tables = reinterpret_cast<const TT *>(a.tables);
+    const uint32_t lb = field_logical_block();
+    const uint32_t t_begin = lb * a.tiles_per_block;
+    const uint32_t t_end = min(t_begin + a.tiles_per_block, ntiles);
+    const s4v ident = mm_identity_frag<CD>(lane);
+    const int nc = (int)b.nc;
+
+    for (uint32_t tile = t_begin + wave; tile < t_end; tile += BWD_THREADS / 64) {
+        const uint32_t m = tile * 16 + s;
+        const bool valid = m < Mc;
+        float u0 = 0.f, u1 = 0.f, u2 = 0.f;
+        if (valid) {
+            u0 = field_unit(a.xyzs[(size_t)m * 3 + 0], a.bmin[0], a.bsize[0]);
+            u1 = field_unit(a.xyzs[(size_t)m * 3 + 1], a.bmin[1], a.bsize[1]);
+            u2 = field_unit(a.xyzs[(size_t)m * 3 + 2], a.bmin[2], a.bsize[2]);
+        }
+        const bool live = valid && !(u0 < 0 || u0 > 1 || u1 < 0 || u1 > 1 || u2 < 0 || u2 > 1);
+
+        // ================= recompute forward, keeping rounded activations ====================
+        s8v xd[1], xc[1];
+        field_encode<TT, CD, false>(lds_lv, tables, u0, u1, u2, live, g, xd[0], xc[0]);
+        f4v h[4];
+        s8v hd[2], hk[2], hc[2], hr1[2], hr2[2];
+        f4v logit[1], c1[1], rgb[1];
+        mm_layer32<CD, 4, 1>(wl + FW_D1, lane, xd, h);
+        mm_pack64<CD, true>(h, hd);
+        mm_layer32<CD, 1, 2>(wl + FW_D2, lane, hd, logit);
+        mm_layer32<CD, 4, 1>(wl + FW_K1, lane, xc, h);
+        mm_pack64<CD, true>(h, hk);
+        mm_layer32<CD, 4, 1>(wl + FW_C1A, lane, xc, h);
+        mm_pack64<CD, true>(h, hc);
+        mm_layer32<CD, 1, 2>(wl + FW_C1B, lane, hc, c1);
+        const s4v c1b = mm_round4<CD, false>(c1[0]);
+        mm_layer16<CD, 4>(wl + FW_R1, lane, c1b, h);
+        mm_pack64<CD, true>(h, hr1);
+        mm_layer32<CD, 4, 2>(wl + FW_R2, lane, hr1, h);
+        mm_pack64<CD, true>(h, hr2);
+        mm_layer32<CD, 1, 2>(wl + FW_R3, lane, hr2, rgb);
+
+        // ================= upstream gradients in B-fragment form (row = 4g + e) ===============
+        s4v dyd, dyr, dyk;
+        {
+            float gd[4] = {0.f, 0.f, 0.f, 0.f}, gr[4] = {0.f, 0.f, 0.f, 0.f}, gk[4] = {0.f, 0.f, 0.f, 0.f};
+            if (valid) {
+                if (g == 0) {
+                    // sigma = exp(logit) * density_scale; trunc_exp backward clamps (tcnn_nerf.py:62-66)
+                    const float x = logit[0][0];
+                    gd[0] = b.grad_sigmas[m] * a.density_scale * expf(fminf(fmaxf(x, -15.0f), 15.0f));
+                }
+                const float *gp = b.grad_rgbs + (size_t)m * a.C_ch;
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const int ch = 4 * g + e;
+                    if ((uint32_t)ch < a.C_ch) {
+                        const float gv = gp[ch];
+                        if (ch < 3) {
+                            const float sg = field_sigmoid(rgb[0][e]);
+                            gr[e] = gv * sg * (1.0f - sg);
+                        } else {
+                            gk[e] = gv;
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; e++) { dyd[e] = MM<CD>::cvt(gd[e]); dyr[e] = MM<CD>::cvt(gr[e]); dyk[e] = MM<CD>::cvt(gk[e]); }
+        }
+
+        // ================= color2: 16 -> 64 -> 64 -> 3 =======================================
+        s8v g2[2], g1[2];
+        s4v gc1;
+        {
+            mm_layer16<CD, 4>(wt + BW_R3T, lane, dyr, h);
+            field_mask_pack<CD>(h, hr2, g2);
+            mm_layer32<CD, 4, 2>(wt + BW_R2T, lane, g2, h);
+            field_mask_pack<CD>(h, hr1, g1);
+            f4v t1[1];
+            mm_layer32<CD, 1, 2>(wt + BW_R1T, lane, g1, t1);
+            gc1 = mm_round4<CD, false>(t1[0]);
+            // wgrads of r3, r2, r1
+            s4v hr2t[4], hr1t[4], g2t[4], g1t[4];
+            field_tr4<CD>(hr2, ident, hr2t);
+            field_tr4<CD>(g2, ident, g2t);
+            const s4v dyrt[1] = {mm_transpose16<CD>(dyr, ident)};
+            field_wgrad<CD, 1, 4>(wg + P_R3, 64, 0, 0, 3, dyrt, hr2t, lane);
+            field_tr4<CD>(hr1, ident, hr1t);
+            field_wgrad<CD, 4, 4>(wg + P_R2, 64, 0, 0, 64, g2t, hr1t, lane);
+            field_tr4<CD>(g1, ident, g1t);
+            const s4v c1t[1] = {mm_transpose16<CD>(c1b, ident)};
+            field_wgrad<CD, 4, 1>(wg + P_R1, 16, 0, 0, 64, g1t, c1t, lane);
+        }
+        // transposed encoder features (shared by the color1 / class / density wgrads)
+        s4v xct[2], xdt[2];
+        field_tr2<CD>(xc, ident, xct);
+        field_tr2<CD>(xd, ident, xdt);
+
+        // ================= color1: 32 -> 64 -> 16, and class: 32 -> 64 -> nc ==================
+        f4v gxc[2];
+        {
+            s8v gh[2];
+            s4v ght[4], hct[4];
+            mm_layer16<CD, 4>(wt + BW_C1BT, lane, gc1, h);
+            field_mask_pack<CD>(h, hc, gh);
+            mm_layer32<CD, 2, 2>(wt + BW_C1AT, lane, gh, gxc);
+            field_tr4<CD>(hc, ident, hct);
+            const s4v gc1t[1] = {mm_transpose16<CD>(gc1, ident)};
+            field_wgrad<CD, 1, 4>(wg + P_C1B, 64, 0, 0, 16, gc1t, hct, lane);
+            field_tr4<CD>(gh, ident, ght);
+            field_wgrad<CD, 4, 2>(wg + P_C1A, 32, 0, 0, 64, ght, xct, lane);
+        }
+        {
+            s8v gh[2];
+            s4v ght[4], hkt[4];
+            mm_layer16<CD, 4>(wt + BW_K2T, lane, dyk, h);
+            field_mask_pack<CD>(h, hk, gh);
+            mm_layer32_acc<CD, 2, 2>(wt + BW_K1T, lane, gh, gxc);
+            field_tr4<CD>(hk, ident, hkt);
+            const s4v dykt[1] = {mm_transpose16<CD>(dyk, ident)};
+            field_wgrad<CD, 1, 4>(wg + P_K2, 64, CLASS_ROW_SHIFT, 0, nc, dykt, hkt, lane);
+            field_tr4<CD>(gh, ident, ght);
+            field_wgrad<CD, 4, 2>(wg + P_K1, 32, 0, 0, 64, ght, xct, lane);
+        }
+        // ================= density: 32 -> 64 -> 1 =============================================
+        f4v gxd[2];
+        {
+            s8v gh[2];
+            s4v ght[4], hdt[4];
+            mm_layer16<CD, 4>(wt + BW_D2T, lane, dyd, h);
+            field_mask_pack<CD>(h, hd, gh);
+            mm_layer32<CD, 2, 2>(wt + BW_D1T, lane, gh, gxd);
+            field_tr4<CD>(hd, ident, hdt);
+            const s4v dydt[1] = {mm_transpose16<CD>(dyd, ident)};
+            field_wgrad<CD, 1, 4>(wg + P_D2, 64, 0, 0, 1, dydt, hdt, lane);
+            field_tr4<CD>(gh, ident, ght);
+            field_wgrad<CD, 4, 2>(wg + P_D1, 32, 0, 0, 64, ght, xdt, lane);
+        }
+
+        // ================= table scatter =======================================================
+        // gxd[t][2*(i&1)+f] is d L / d feature f of level lvl[i] (t = i >> 1): same lane<->level map
+        // as the forward encode.
+        if (live && (b.train_density || b.train_color)) {
+            const int lvl[4] = {2 * g, 2 * g + 1, 8 + 2 * g, 9 + 2 * g};
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const NsrLevel lv = lds_lv[lvl[i]];
+                const int t = i >> 1, e0 = 2 * (i & 1);
+                field_scatter_level(lv, b.grad_tables, u0, u1, u2, gxd[t][e0], gxd[t][e0 + 1], gxc[t][e0], gxc[t][e0 + 1],
+                                    b.train_density != 0, b.train_color != 0);
+            }
+        }
+    }
+
+    // ---- flush the workgroup's weight gradients ---------------------------------------------------
+    __syncthreads();
+    if (b.grad_mlp) {
+        for (int i = threadIdx.x; i < P_TOTAL; i += BWD_THREADS) {
+            const float v = wg[i];
+            if (v != 0.0f) atomicAdd(b.grad_mlp + i, v);
+        }
+    }
+}
+
+extern "C" {
+
+int nsr_field_backward(const nsr_field_desc *desc, const void *tables, const float *mlp_params, const float *xyzs, uint32_t M,
+                       const int32_t *m_dev, const float *grad_sigmas, const float *grad_rgbs, float *grad_tables,
+                       float *grad_mlp, int train_density_table, int train_color_table, nsr_stream_t stream) {
+    if (M == 0) return NSR_OK;
+    NSR_CHECK_PTR(desc); NSR_CHECK_PTR(tables); NSR_CHECK_PTR(mlp_params); NSR_CHECK_PTR(xyzs);
+    NSR_CHECK_PTR(grad_sigmas); NSR_CHECK_PTR(grad_rgbs);
+    if ((train_density_table || train_color_table) && grad_tables == nullptr) return NSR_ERR_INVALID_ARG;
+    FieldBwdArgs b;
+    uint32_t nblocks;
+    const int st = field_fill_args(desc, b.f, M, nblocks);
+    if (st != NSR_OK) return st;
+    if ((uintptr_t)tables & 15u) return NSR_ERR_INVALID_ARG;
+    // one 512-thread workgroup per CU (120.5 KiB of LDS): at most 256 resident, each walks a
+    // contiguous range of tiles
+    const uint32_t ntiles = (M + 15) / 16;
+    nblocks = (ntiles + 7) / 8;
+    if (nblocks > 256) nblocks = 256;
+    b.f.tiles_per_block = (ntiles + nblocks - 1) / nblocks;
+    b.f.tables = tables; b.f.params = mlp_params; b.f.xyzs = xyzs; b.f.m_dev = m_dev; b.f.sigmas = nullptr; b.f.rgbs = nullptr;
+    b.grad_sigmas = grad_sigmas; b.grad_rgbs = grad_rgbs; b.grad_tables = grad_tables; b.grad_mlp = grad_mlp;
+    b.train_density = train_density_table; b.train_color = train_color_table; b.nc = desc->num_classes;
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid(nblocks), block(BWD_THREADS);
+#define NSR_BWD_LAUNCH(TT, CD)                                                                                \
+    do {                                                                                                       \
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_field_bwd<TT, CD>),                          \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)BWD_LDS_BYTES) != hipSuccess) \
+            return NSR_ERR_LAUNCH;                                                                             \
+        hipLaunchKernelGGL((k_field_bwd<TT, CD>), grid, block, BWD_LDS_BYTES, s, b);                           \
+        return nsr_launch_status();                                                                            \
+    } while (0)
+    if (desc->table_dtype == NSR_F32 && desc->compute_dtype == NSR_F16) NSR_BWD_LAUNCH(float, NSR_F16);
+    if (desc->table_dtype == NSR_F32 && desc->compute_dtype == NSR_BF16) NSR_BWD_LAUNCH(float, NSR_BF16);
+    if (desc->table_dtype == NSR_F16 && desc->compute_dtype == NSR_F16) NSR_BWD_LAUNCH(_Float16, NSR_F16);
+    if (desc->table_dtype == NSR_F16 && desc->compute_dtype == NSR_BF16) NSR_BWD_LAUNCH(_Float16, NSR_BF16);
+#undef NSR_BWD_LAUNCH
+    return NSR_ERR_UNSUPPORTED;
+}
+
+}   // extern "C"

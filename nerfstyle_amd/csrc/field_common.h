@@ -1,0 +1,183 @@
+// Shared pieces of the fused field kernels (forward: field.hip, backward: field_bwd.hip).
+#pragma once
+#include <hip/hip_fp16.h>
+
+#include "mfma_tiles.h"
+
+// ---- parameter layout (floats) inside mlp_params: density, color1, color2, class ------------
+constexpr int P_D1 = 0;        // 64 x 32
+constexpr int P_D2 = 2048;     // 16 x 64 (row 0 = logit)
+constexpr int P_C1A = 3072;    // 64 x 32
+constexpr int P_C1B = 5120;    // 16 x 64
+constexpr int P_R1 = 6144;     // 64 x 16
+constexpr int P_R2 = 7168;     // 64 x 64
+constexpr int P_R3 = 11264;    // 16 x 64 (rows 0..2 = rgb)
+constexpr int P_K1 = 12288;    // 64 x 32
+constexpr int P_K2 = 14336;    // 16 x 64 (rows 0..nc-1 = classes)
+constexpr int P_TOTAL = 15360;
+
+// ---- forward LDS image (units: shorts).  frag32 = 512 shorts, frag16 = 256 shorts ----------
+constexpr int FW_D1 = 0, FW_D2 = 2048, FW_C1A = 3072, FW_C1B = 5120, FW_K1 = 6144, FW_K2 = 8192, FW_R2 = 9216,
+              FW_R3 = 13312, FW_R1 = 14336, FW_TOTAL = 15360, FW_SIGMA_TOTAL = 3072;
+// class logits live in rows 3..3+nc-1 of their output tile so that (row == output channel) and
+// lane (s,g) stores channels 4g..4g+3 of rgbs[m, :] as one 16-byte piece.
+constexpr int CLASS_ROW_SHIFT = 3;
+
+struct FieldArgs {
+    const void *tables;
+    const float *params;
+    const float *xyzs;
+    const int32_t *m_dev;
+    uint32_t M;
+    float *sigmas;
+    float *rgbs;
+    float bmin[3], bsize[3];
+    float density_scale;
+    uint32_t C_ch;
+    uint32_t tiles_per_block;
+    NsrLevel lv[16];
+};
+
+template <int CD, bool SIGMA_ONLY>
+__device__ __forceinline__ void field_build_fw(short *lds, const float *__restrict__ p) {
+    mm_build_frags<CD>(lds + FW_D1, p + P_D1, 64, 32, 4, 32, false, 0, true);
+    mm_build_frags<CD>(lds + FW_D2, p + P_D2, 16, 64, 1, 64, false, 0, true);
+    if (!SIGMA_ONLY) {
+        mm_build_frags<CD>(lds + FW_C1A, p + P_C1A, 64, 32, 4, 32, false, 0, true);
+        mm_build_frags<CD>(lds + FW_C1B, p + P_C1B, 16, 64, 1, 64, false, 0, true);
+        mm_build_frags<CD>(lds + FW_K1, p + P_K1, 64, 32, 4, 32, false, 0, true);
+        mm_build_frags<CD>(lds + FW_K2, p + P_K2, 16, 64, 1, 64, false, CLASS_ROW_SHIFT, true);
+        mm_build_frags<CD>(lds + FW_R2, p + P_R2, 64, 64, 4, 64, false, 0, true);
+        mm_build_frags<CD>(lds + FW_R3, p + P_R3, 16, 64, 1, 64, false, 0, true);
+        mm_build_frags<CD>(lds + FW_R1, p + P_R1, 64, 16, 4, 16, false, 0, false);
+    }
+}
+
+// Encoder input of a world position: BBox.normalize (common.py:276-288) then GridEncoder's
+// (x + bound) / (2 * bound) with bound = 1 (grid.py:177).  Same op order as the oracle.
+__device__ __forceinline__ float field_unit(float x, float mn, float sz) {
+#pragma clang fp contract(off)
+    const float xn = (x - mn) / sz;
+    return (xn + 1.0f) / 2.0f;
+}
+
+template <typename TT> struct RowLd;
+template <> struct RowLd<float> {
+    // one interleaved row = [d0 d1 c0 c1] fp32 = 16 bytes
+    static __device__ __forceinline__ float4 full(const float *t, uint32_t row) {
+        return reinterpret_cast<const float4 *>(t)[row];
+    }
+    static __device__ __forceinline__ float2 dens(const float *t, uint32_t row) {
+        return reinterpret_cast<const float2 *>(t)[(size_t)row * 2];
+    }
+};
+template <> struct RowLd<_Float16> {
+    static __device__ __forceinline__ float4 full(const _Float16 *t, uint32_t row) {
+        const h4v v = reinterpret_cast<const h4v *>(t)[row];
+        return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+    }
+    static __device__ __forceinline__ float2 dens(const _Float16 *t, uint32_t row) {
+        typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+        const h2v v = reinterpret_cast<const h2v *>(t)[(size_t)row * 2];
+        return make_float2((float)v[0], (float)v[1]);
+    }
+};
+
+// Trilinear interpolation of one level for both encoders (gridencoder.cu:134-181, align_corners
+// = True, style = 0 on this path: networks/tcnn_nerf.py:26-35).
+template <typename TT, bool SIGMA_ONLY>
+__device__ __forceinline__ float4 field_encode_level(const NsrLevel &lv, const TT *__restrict__ tables, float u0, float u1,
+                                                     float u2, bool live) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (live) {
+        float f[3];
+        uint32_t c[3];
+        nsr_grid_locate(u0, lv.resolution, 1, f[0], c[0]);
+        nsr_grid_locate(u1, lv.resolution, 1, f[1], c[1]);
+        nsr_grid_locate(u2, lv.resolution, 1, f[2], c[2]);
+        uint32_t rows[8];
+        float w[8];
+#pragma unroll
+        for (uint32_t idx = 0; idx < 8; idx++) {
+            float ww = 1;
+            uint32_t p[3];
+#pragma unroll
+            for (uint32_t d = 0; d < 3; d++) {
+                if ((idx & (1u << d)) == 0) { ww *= 1 - f[d]; p[d] = c[d]; }
+                else { ww *= f[d]; p[d] = c[d] + 1; }
+            }
+            w[idx] = ww;
+            rows[idx] = lv.offset + nsr_grid_row(lv, p[0], p[1], p[2], 0u);
+        }
+        if (SIGMA_ONLY) {
+            float2 v[8];
+#pragma unroll
+            for (int idx = 0; idx < 8; idx++) v[idx] = RowLd<TT>::dens(tables, rows[idx]);
+#pragma unroll
+            for (int idx = 0; idx < 8; idx++) { acc.x += w[idx] * v[idx].x; acc.y += w[idx] * v[idx].y; }
+        } else {
+            float4 v[8];
+#pragma unroll
+            for (int idx = 0; idx < 8; idx++) v[idx] = RowLd<TT>::full(tables, rows[idx]);
+#pragma unroll
+            for (int idx = 0; idx < 8; idx++) {
+                acc.x += w[idx] * v[idx].x; acc.y += w[idx] * v[idx].y;
+                acc.z += w[idx] * v[idx].z; acc.w += w[idx] * v[idx].w;
+            }
+        }
+    }
+    return acc;
+}
+
+// Encodes this lane's four levels; returns the two K=32 B fragments (density, colour).
+template <typename TT, int CD, bool SIGMA_ONLY>
+__device__ __forceinline__ void field_encode(const NsrLevel *lds_lv, const TT *__restrict__ tables, float u0, float u1, float u2,
+                                             bool live, int g, s8v &xd, s8v &xc) {
+    const int lvl[4] = {2 * g, 2 * g + 1, 8 + 2 * g, 9 + 2 * g};
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const NsrLevel lv = lds_lv[lvl[i]];
+        const float4 a = field_encode_level<TT, SIGMA_ONLY>(lv, tables, u0, u1, u2, live);
+        xd[2 * i + 0] = MM<CD>::cvt(a.x);
+        xd[2 * i + 1] = MM<CD>::cvt(a.y);
+        xc[2 * i + 0] = MM<CD>::cvt(a.z);
+        xc[2 * i + 1] = MM<CD>::cvt(a.w);
+    }
+}
+
+__device__ __forceinline__ float field_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// XCD-aware logical block id: hardware deals blocks round-robin over the 8 XCDs, so blocks b and
+// b+8 share an L2.  Give each XCD one contiguous eighth of the tiles (neighbouring tiles =
+// neighbouring samples/rays = shared coarse-level table lines).  Bijective for any grid size.
+__device__ __forceinline__ uint32_t field_logical_block() {
+    const uint32_t nb = gridDim.x, b = blockIdx.x;
+    const uint32_t q = nb / 8, r = nb % 8, xcd = b % 8, i = b / 8;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
+}
+
+
+static int field_fill_args(const nsr_field_desc *d, FieldArgs &a, uint32_t M, uint32_t &nblocks) {
+    if (d->L != 16) return NSR_ERR_UNSUPPORTED;             // 32 features = two K=32 halves per encoder
+    if (d->num_classes > 13) return NSR_ERR_UNSUPPORTED;    // class rows 3..15 of one 16-row tile
+    if (d->offsets == nullptr) return NSR_ERR_INVALID_ARG;
+    NsrLevels lv;
+    nsr_fill_levels(&lv, d->offsets, 16, d->S, d->H, 0u);
+    for (int l = 0; l < 16; l++) {
+        a.lv[l] = lv.lv[l];
+        if (lv.lv[l].size == 0) return NSR_ERR_INVALID_ARG;
+    }
+    for (int i = 0; i < 3; i++) { a.bmin[i] = d->bbox_min[i]; a.bsize[i] = d->bbox_size[i]; }
+    a.density_scale = d->density_scale;
+    a.C_ch = 3 + d->num_classes;
+    a.M = M;
+    const uint32_t ntiles = (M + 15) / 16;
+    // >= 8 tiles per wave so the per-block weight-image build amortises; <= 8 blocks per CU
+    uint32_t nb = (ntiles + 31) / 32;
+    if (nb > 2048) nb = 2048;
+    if (nb == 0) nb = 1;
+    nblocks = nb;
+    a.tiles_per_block = (ntiles + nb - 1) / nb;
+    return NSR_OK;
+}
+

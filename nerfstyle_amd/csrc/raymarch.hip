@@ -1,0 +1,759 @@
+// Occupancy-grid ray march, sample compaction and alpha compositing for gfx950.
+// Behaviour follows hkust-vgd/nerfstyle raymarching/src/raymarching.cu (cited per function);
+// the structure does not: offsets come from a wave64 shuffle scan + one look-up of per-block
+// totals (deterministic, no atomics), the composite backward keeps its running sums in
+// registers (no rgbs_buf round trip), and every entry point takes an explicit stream.
+#include "nsr_common.h"
+
+#define RM_BLOCK 256
+#define RM_SQRT3 1.7320508075688772f
+
+// ---------------------------------------------------------------------------------------------
+// small device helpers
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float rm_clamp(float x, float lo, float hi) { return fminf(hi, fmaxf(lo, x)); }
+__device__ __forceinline__ float rm_sign(float x) { return copysignf(1.0f, x); }
+
+// raymarching.cu:56-81
+__device__ __forceinline__ uint32_t rm_expand_bits(uint32_t v) {
+    v = (v * 0x00010001u) & 0xFF0000FFu;
+    v = (v * 0x00000101u) & 0x0F00F00Fu;
+    v = (v * 0x00000011u) & 0xC30C30C3u;
+    v = (v * 0x00000005u) & 0x49249249u;
+    return v;
+}
+__device__ __forceinline__ uint32_t rm_morton3d(uint32_t x, uint32_t y, uint32_t z) {
+    return rm_expand_bits(x) | (rm_expand_bits(y) << 1) | (rm_expand_bits(z) << 2);
+}
+__device__ __forceinline__ uint32_t rm_morton3d_invert(uint32_t x) {
+    x = x & 0x49249249;
+    x = (x | (x >> 2)) & 0xc30c30c3;
+    x = (x | (x >> 4)) & 0x0f00f00f;
+    x = (x | (x >> 8)) & 0xff0000ff;
+    x = (x | (x >> 16)) & 0x0000ffff;
+    return x;
+}
+
+// wave64 inclusive scan by shuffles, then a block scan over the (<= 16) wave totals in LDS.
+// Returns the exclusive prefix of v inside the block and the block total in `total`.
+__device__ __forceinline__ uint32_t rm_block_exclusive_scan(uint32_t v, uint32_t *lds_wave_sums, uint32_t &total) {
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t up = __shfl_up(incl, off, 64);
+        if (lane >= (uint32_t)off) incl += up;
+    }
+    if (lane == 63) lds_wave_sums[wave] = incl;
+    __syncthreads();
+    const uint32_t nw = blockDim.x >> 6;
+    uint32_t wave_prefix = 0, tot = 0;
+    for (uint32_t w = 0; w < nw; w++) {
+        const uint32_t s = lds_wave_sums[w];
+        if (w < wave) wave_prefix += s;
+        tot += s;
+    }
+    __syncthreads();
+    total = tot;
+    return wave_prefix + incl - v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// marching core (raymarching.cu:460-500, 530-588, 1059-1119)
+// ---------------------------------------------------------------------------------------------
+struct RmRay {
+    float ox, oy, oz, dx, dy, dz, rdx, rdy, rdz;
+};
+struct RmCfg {
+    float bound, dt_gamma, dt_min, dt_max, rH, H3, Hf, Cf;
+    uint32_t H;
+    const uint8_t *grid;
+};
+
+__device__ __forceinline__ RmCfg rm_cfg(float bound, float dt_gamma, uint32_t max_steps, uint32_t C, uint32_t H,
+                                        const uint8_t *grid) {
+    RmCfg c;
+    c.bound = bound;
+    c.dt_gamma = dt_gamma;
+    c.dt_min = 2 * RM_SQRT3 / (float)max_steps;               // :446
+    c.dt_max = 2 * RM_SQRT3 * (float)(1 << (C - 1)) / (float)H;  // :447
+    c.rH = 1 / (float)H;
+    c.H3 = (float)(H * H * H);
+    c.Hf = (float)H;
+    c.Cf = (float)C;
+    c.H = H;
+    c.grid = grid;
+    return c;
+}
+
+__device__ __forceinline__ int rm_mip(float v, float max_cascade) {
+    int e;
+    frexpf(v, &e);
+    return (int)fminf(max_cascade - 1, fmaxf(0.0f, (float)e));
+}
+
+// Evaluates the sample at parameter t.  Same operation order as the reference (and the oracle);
+// contraction is off so that every rounding matches the restatement bit for bit.
+__device__ __forceinline__ bool rm_probe(const RmRay &r, const RmCfg &c, float t, float &x, float &y, float &z,
+                                         float &dt, float &tt) {
+#pragma clang fp contract(off)
+    x = rm_clamp(r.ox + t * r.dx, -c.bound, c.bound);
+    y = rm_clamp(r.oy + t * r.dy, -c.bound, c.bound);
+    z = rm_clamp(r.oz + t * r.dz, -c.bound, c.bound);
+    dt = rm_clamp(t * c.dt_gamma, c.dt_min, c.dt_max);
+    const int m1 = rm_mip(fmaxf(fabsf(x), fmaxf(fabsf(y), fabsf(z))), c.Cf);   // :42-47
+    const int m2 = rm_mip((float)((double)(dt * c.Hf) * 0.5), c.Cf);             // :49-54
+    const int level = max(m1, m2);
+    const float mip_bound = fminf(scalbnf(1.0f, level), c.bound);
+    const float mip_rbound = 1 / mip_bound;
+    // :475-477 -- double product, narrowed by clamp(), truncated
+    const int nx = (int)rm_clamp((float)(0.5 * (double)(x * mip_rbound + 1) * (double)c.H), 0.0f, (float)(c.H - 1));
+    const int ny = (int)rm_clamp((float)(0.5 * (double)(y * mip_rbound + 1) * (double)c.H), 0.0f, (float)(c.H - 1));
+    const int nz = (int)rm_clamp((float)(0.5 * (double)(z * mip_rbound + 1) * (double)c.H), 0.0f, (float)(c.H - 1));
+    const uint32_t index = (uint32_t)((float)level * c.H3 + (float)rm_morton3d(nx, ny, nz));   // :479
+    const bool occ = c.grid[index / 8] & (1 << (index % 8));
+    if (!occ) {
+        // :491-495
+        const float tx = ((((float)nx + 0.5f + 0.5f * rm_sign(r.dx)) * c.rH * 2 - 1) * mip_bound - x) * r.rdx;
+        const float ty = ((((float)ny + 0.5f + 0.5f * rm_sign(r.dy)) * c.rH * 2 - 1) * mip_bound - y) * r.rdy;
+        const float tz = ((((float)nz + 0.5f + 0.5f * rm_sign(r.dz)) * c.rH * 2 - 1) * mip_bound - z) * r.rdz;
+        tt = t + fmaxf(0.0f, fminf(tx, fminf(ty, tz)));
+    }
+    return occ;
+}
+
+__device__ __forceinline__ void rm_skip(const RmCfg &c, float &t, float tt) {
+#pragma clang fp contract(off)
+    do { t += rm_clamp(t * c.dt_gamma, c.dt_min, c.dt_max); } while (t < tt);
+}
+
+__device__ __forceinline__ RmRay rm_load_ray(const float *rays_o, const float *rays_d, uint32_t n) {
+    RmRay r;
+    r.ox = rays_o[n * 3 + 0]; r.oy = rays_o[n * 3 + 1]; r.oz = rays_o[n * 3 + 2];
+    r.dx = rays_d[n * 3 + 0]; r.dy = rays_d[n * 3 + 1]; r.dz = rays_d[n * 3 + 2];
+    r.rdx = 1 / r.dx; r.rdy = 1 / r.dy; r.rdz = 1 / r.dz;
+    return r;
+}
+
+// ---------------------------------------------------------------------------------------------
+// utilities
+// ---------------------------------------------------------------------------------------------
+// raymarching.cu:190-244
+__global__ void k_near_far_from_aabb(const float *__restrict__ rays_o, const float *__restrict__ rays_d,
+                                     const float *__restrict__ aabb, uint32_t N, float min_near,
+                                     float *__restrict__ nears, float *__restrict__ fars) {
+#pragma clang fp contract(off)
+    const float a0 = aabb[0], a1 = aabb[1], a2 = aabb[2], a3 = aabb[3], a4 = aabb[4], a5 = aabb[5];
+    for (uint32_t n = blockIdx.x * blockDim.x + threadIdx.x; n < N; n += gridDim.x * blockDim.x) {
+        const RmRay r = rm_load_ray(rays_o, rays_d, n);
+        const float big = 3.402823466e+38f;
+        float near = (a0 - r.ox) * r.rdx, far = (a3 - r.ox) * r.rdx;
+        if (near > far) { const float c = near; near = far; far = c; }
+        float near_y = (a1 - r.oy) * r.rdy, far_y = (a4 - r.oy) * r.rdy;
+        if (near_y > far_y) { const float c = near_y; near_y = far_y; far_y = c; }
+        if (near > far_y || near_y > far) { nears[n] = big; fars[n] = big; continue; }
+        if (near_y > near) near = near_y;
+        if (far_y < far) far = far_y;
+        float near_z = (a2 - r.oz) * r.rdz, far_z = (a5 - r.oz) * r.rdz;
+        if (near_z > far_z) { const float c = near_z; near_z = far_z; far_z = c; }
+        if (near > far_z || near_z > far) { nears[n] = big; fars[n] = big; continue; }
+        if (near_z > near) near = near_z;
+        if (far_z < far) far = far_z;
+        if (near < min_near) near = min_near;
+        nears[n] = near;
+        fars[n] = far;
+    }
+}
+
+// raymarching.cu:313-325
+__global__ void k_morton3d(const int32_t *__restrict__ coords, uint32_t N, int32_t *__restrict__ indices) {
+    for (uint32_t n = blockIdx.x * blockDim.x + threadIdx.x; n < N; n += gridDim.x * blockDim.x)
+        indices[n] = (int32_t)rm_morton3d((uint32_t)coords[n * 3], (uint32_t)coords[n * 3 + 1],
+                                          (uint32_t)coords[n * 3 + 2]);
+}
+
+// raymarching.cu:336-353
+__global__ void k_morton3d_invert(const int32_t *__restrict__ indices, uint32_t N, int32_t *__restrict__ coords) {
+    for (uint32_t n = blockIdx.x * blockDim.x + threadIdx.x; n < N; n += gridDim.x * blockDim.x) {
+        const int32_t ind = indices[n];
+        coords[n * 3 + 0] = (int32_t)rm_morton3d_invert((uint32_t)(ind >> 0));
+        coords[n * 3 + 1] = (int32_t)rm_morton3d_invert((uint32_t)(ind >> 1));
+        coords[n * 3 + 2] = (int32_t)rm_morton3d_invert((uint32_t)(ind >> 2));
+    }
+}
+
+// raymarching.cu:366-388.  One thread per output byte, 8 floats in as two 16-byte loads.
+__global__ void k_packbits(const float *__restrict__ grid, uint32_t N, float thresh, uint8_t *__restrict__ bitfield) {
+    for (uint32_t n = blockIdx.x * blockDim.x + threadIdx.x; n < N; n += gridDim.x * blockDim.x) {
+        const float4 a = reinterpret_cast<const float4 *>(grid)[(size_t)n * 2];
+        const float4 b = reinterpret_cast<const float4 *>(grid)[(size_t)n * 2 + 1];
+        uint32_t bits = 0;
+        bits |= (a.x > thresh) ? 1u : 0u;
+        bits |= (a.y > thresh) ? 2u : 0u;
+        bits |= (a.z > thresh) ? 4u : 0u;
+        bits |= (a.w > thresh) ? 8u : 0u;
+        bits |= (b.x > thresh) ? 16u : 0u;
+        bits |= (b.y > thresh) ? 32u : 0u;
+        bits |= (b.z > thresh) ? 64u : 0u;
+        bits |= (b.w > thresh) ? 128u : 0u;
+        bitfield[n] = (uint8_t)bits;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// training march: count -> scan -> emit
+// ---------------------------------------------------------------------------------------------
+// pass 1 (raymarching.cu:455-501): per-ray sample count, per-block total.
+__global__ void __launch_bounds__(RM_BLOCK)
+k_march_count(const float *__restrict__ rays_o, const float *__restrict__ rays_d, const uint8_t *__restrict__ grid,
+              float bound, float dt_gamma, uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H,
+              const float *__restrict__ nears, const float *__restrict__ fars, const float *__restrict__ noises,
+              uint32_t *__restrict__ counts, uint32_t *__restrict__ block_sums) {
+    __shared__ uint32_t wave_sums[RM_BLOCK / 64];
+    const uint32_t n = blockIdx.x * RM_BLOCK + threadIdx.x;
+    uint32_t num_steps = 0;
+    if (n < N) {
+        const RmCfg c = rm_cfg(bound, dt_gamma, max_steps, C, H, grid);
+        const RmRay r = rm_load_ray(rays_o, rays_d, n);
+        const float far = fars[n];
+        float t = nears[n];
+        {
+#pragma clang fp contract(off)
+            const float noise = noises ? noises[n] : 0.0f;
+            t += rm_clamp(t * dt_gamma, c.dt_min, c.dt_max) * noise;   // :452
+        }
+        float x, y, z, dt, tt;
+        while (t < far && num_steps < max_steps) {
+            if (rm_probe(r, c, t, x, y, z, dt, tt)) {
+                num_steps++;
+                t += dt;
+            } else {
+                rm_skip(c, t, tt);
+            }
+        }
+        counts[n] = num_steps;
+    }
+    uint32_t total;
+    rm_block_exclusive_scan(num_steps, wave_sums, total);
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
+}
+
+// Exclusive scan of the per-block totals by ONE block; also applies the reference's counter
+// semantics (atomicAdd(counter, num_steps) / atomicAdd(counter+1, 1), :506-507): block bases
+// start at the incoming counter[0]; counter[0] += total, counter[1] += N.
+__global__ void __launch_bounds__(1024)
+k_scan_block_sums(uint32_t *__restrict__ block_sums, uint32_t nblocks, int32_t *__restrict__ counter, uint32_t N) {
+    __shared__ uint32_t wave_sums[1024 / 64];
+    __shared__ uint32_t carry_s;
+    if (threadIdx.x == 0) carry_s = counter ? (uint32_t)counter[0] : 0u;
+    __syncthreads();
+    const uint32_t base0 = carry_s;
+    uint32_t carry = base0;
+    for (uint32_t start = 0; start < nblocks; start += 1024) {
+        const uint32_t i = start + threadIdx.x;
+        const uint32_t v = i < nblocks ? block_sums[i] : 0u;
+        uint32_t total;
+        const uint32_t ex = rm_block_exclusive_scan(v, wave_sums, total);
+        if (i < nblocks) block_sums[i] = carry + ex;
+        carry += total;
+    }
+    if (threadIdx.x == 0 && counter) {
+        counter[0] = (int32_t)carry;
+        counter[1] += (int32_t)N;
+    }
+}
+
+// pass 2 (raymarching.cu:505-588): offsets from the scan, then re-march and emit.
+__global__ void __launch_bounds__(RM_BLOCK)
+k_march_emit(const float *__restrict__ rays_o, const float *__restrict__ rays_d, const float *__restrict__ z_hats,
+             const uint8_t *__restrict__ grid, float bound, float dt_gamma, uint32_t max_steps, int is_ndc,
+             uint32_t N, uint32_t C, uint32_t H, uint32_t M, const float *__restrict__ nears,
+             const float *__restrict__ fars, const float *__restrict__ noises, const uint32_t *__restrict__ counts,
+             const uint32_t *__restrict__ block_bases, uint32_t ray_base, float *__restrict__ xyzs,
+             float *__restrict__ dirs, float *__restrict__ deltas, int32_t *__restrict__ rays) {
+    __shared__ uint32_t wave_sums[RM_BLOCK / 64];
+    const uint32_t n = blockIdx.x * RM_BLOCK + threadIdx.x;
+    const uint32_t num_steps = n < N ? counts[n] : 0u;
+    uint32_t total;
+    const uint32_t point_index = block_bases[blockIdx.x] + rm_block_exclusive_scan(num_steps, wave_sums, total);
+    if (n >= N) return;
+    const uint32_t ray_index = ray_base + n;
+    rays[ray_index * 3 + 0] = (int32_t)n;
+    rays[ray_index * 3 + 1] = (int32_t)point_index;
+    rays[ray_index * 3 + 2] = (int32_t)num_steps;
+    if (num_steps == 0) return;
+    if (point_index + num_steps >= M) return;   // :517
+
+    const RmCfg c = rm_cfg(bound, dt_gamma, max_steps, C, H, grid);
+    const RmRay r = rm_load_ray(rays_o, rays_d, n);
+    const float far = fars[n];
+    float t = nears[n];
+    {
+#pragma clang fp contract(off)
+        const float noise = noises ? noises[n] : 0.0f;
+        t += rm_clamp(t * dt_gamma, c.dt_min, c.dt_max) * noise;
+    }
+    float *pxyz = xyzs + (size_t)point_index * 3;
+    float *pdir = dirs ? dirs + (size_t)point_index * 3 : nullptr;
+    float *pdel = deltas + (size_t)point_index * 4;
+    uint32_t step = 0;
+    float last_t = t;
+    float last_z = rm_clamp(r.oz + t * r.dz, -bound, bound);
+    float x, y, z, dt, tt;
+    while (t < far && step < num_steps) {
+        if (rm_probe(r, c, t, x, y, z, dt, tt)) {
+#pragma clang fp contract(off)
+            pxyz[0] = x; pxyz[1] = y; pxyz[2] = z;
+            if (pdir) { pdir[0] = r.dx; pdir[1] = r.dy; pdir[2] = r.dz; pdir += 3; }
+            t += dt;
+            if (is_ndc) {
+                const float new_z = rm_clamp(r.oz + t * r.dz, -bound, bound);
+                const float zh = z_hats[n];
+                reinterpret_cast<float4 *>(pdel)[0] = make_float4(dt, t - last_t, (2 / (new_z - 1) - 2 / (z - 1)) / zh,
+                                                                  (2 / (new_z - 1) - 2 / (last_z - 1)) / zh);
+                last_z = z;   // :570
+            } else {
+                reinterpret_cast<float2 *>(pdel)[0] = make_float2(dt, t - last_t);
+            }
+            last_t = t;
+            pxyz += 3; pdel += 4;
+            step++;
+        } else {
+            rm_skip(c, t, tt);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// compositing (training)
+// ---------------------------------------------------------------------------------------------
+#define RM_MAXC 16
+
+// raymarching.cu:806-879
+__global__ void __launch_bounds__(RM_BLOCK)
+k_composite_train_fwd(const float *__restrict__ sigmas, const float *__restrict__ rgbs, const float *__restrict__ deltas,
+                      const int32_t *__restrict__ rays, uint32_t M, uint32_t N, uint32_t C, float T_thresh, int is_ndc,
+                      float *__restrict__ weights_sum, float *__restrict__ depth, float *__restrict__ image) {
+    const uint32_t n = blockIdx.x * RM_BLOCK + threadIdx.x;
+    if (n >= N) return;
+    const uint32_t index = (uint32_t)rays[n * 3], offset = (uint32_t)rays[n * 3 + 1], num_steps = (uint32_t)rays[n * 3 + 2];
+    float acc[RM_MAXC];
+#pragma unroll
+    for (int i = 0; i < RM_MAXC; i++) acc[i] = 0.0f;
+    float T = 1.0f, ws = 0.0f, t = 0.0f, d = 0.0f;
+    if (!(num_steps == 0 || offset + num_steps >= M)) {
+        const float *s = sigmas + offset;
+        const float *rgb = rgbs + (size_t)offset * C;
+        const float *dl = deltas + (size_t)offset * 4;
+        for (uint32_t step = 0; step < num_steps; step++) {
+            const float alpha = 1.0f - __expf(-s[step] * (is_ndc ? dl[step * 4 + 2] : dl[step * 4 + 0]));
+            const float weight = alpha * T;
+#pragma unroll
+            for (int i = 0; i < RM_MAXC; i++)
+                if ((uint32_t)i < C) acc[i] += weight * rgb[(size_t)step * C + i];
+            t += (is_ndc ? dl[step * 4 + 3] : dl[step * 4 + 1]);
+            d += weight * t;
+            ws += weight;
+            T *= 1.0f - alpha;
+            if (T < T_thresh) break;   // :862
+        }
+    }
+    weights_sum[index] = ws;
+    depth[index] = d;
+#pragma unroll
+    for (int i = 0; i < RM_MAXC; i++)
+        if ((uint32_t)i < C) image[(size_t)index * C + i] = acc[i];
+}
+
+// raymarching.cu:904-986.  rgbs_buf lives in registers.
+__global__ void __launch_bounds__(RM_BLOCK)
+k_composite_train_bwd(const float *__restrict__ grad_weights_sum, const float *__restrict__ grad_image,
+                      const float *__restrict__ sigmas, const float *__restrict__ rgbs, const float *__restrict__ deltas,
+                      const int32_t *__restrict__ rays, int is_ndc, const float *__restrict__ weights_sum,
+                      const float *__restrict__ image, uint32_t M, uint32_t N, uint32_t C, float T_thresh,
+                      float *__restrict__ grad_sigmas, float *__restrict__ grad_rgbs) {
+    const uint32_t n = blockIdx.x * RM_BLOCK + threadIdx.x;
+    if (n >= N) return;
+    const uint32_t index = (uint32_t)rays[n * 3], offset = (uint32_t)rays[n * 3 + 1], num_steps = (uint32_t)rays[n * 3 + 2];
+    if (num_steps == 0 || offset + num_steps >= M) return;
+    float buf[RM_MAXC], gim[RM_MAXC], im[RM_MAXC];
+#pragma unroll
+    for (int i = 0; i < RM_MAXC; i++) {
+        buf[i] = 0.0f;
+        gim[i] = (uint32_t)i < C ? grad_image[(size_t)index * C + i] : 0.0f;
+        im[i] = (uint32_t)i < C ? image[(size_t)index * C + i] : 0.0f;
+    }
+    const float gws = grad_weights_sum[index];
+    const float ws_final = weights_sum[index];
+    const float *s = sigmas + offset;
+    const float *rgb = rgbs + (size_t)offset * C;
+    const float *dl = deltas + (size_t)offset * 4;
+    float *gs = grad_sigmas + offset;
+    float *grgb = grad_rgbs + (size_t)offset * C;
+    float T = 1.0f;
+    for (uint32_t step = 0; step < num_steps; step++) {
+        const float delta = is_ndc ? dl[step * 4 + 2] : dl[step * 4 + 0];
+        const float alpha = 1.0f - __expf(-s[step] * delta);
+        const float weight = alpha * T;
+        float c[RM_MAXC];
+#pragma unroll
+        for (int i = 0; i < RM_MAXC; i++) {
+            c[i] = (uint32_t)i < C ? rgb[(size_t)step * C + i] : 0.0f;
+            buf[i] += weight * c[i];
+        }
+        T *= 1.0f - alpha;
+        if (T < T_thresh) break;   // :961
+        float gsum = 0.0f;
+#pragma unroll
+        for (int i = 0; i < RM_MAXC; i++) {
+            if ((uint32_t)i < C) {
+                grgb[(size_t)step * C + i] = gim[i] * weight;
+                gsum += gim[i] * (T * c[i] - (im[i] - buf[i]));
+            }
+        }
+        gs[step] = delta * (gsum + gws * (1 - ws_final));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// inference march / composite (raymarching.cu:1004-1120, 1133-1231)
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(RM_BLOCK)
+k_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t *__restrict__ rays_alive, const float *__restrict__ rays_t,
+             const float *__restrict__ rays_o, const float *__restrict__ rays_d, const float *__restrict__ z_hats,
+             float bound, float dt_gamma, uint32_t max_steps, int is_ndc, uint32_t C, uint32_t H,
+             const uint8_t *__restrict__ grid, const float *__restrict__ fars, float *__restrict__ xyzs,
+             float *__restrict__ dirs, float *__restrict__ deltas, const float *__restrict__ noises) {
+    const uint32_t n = blockIdx.x * RM_BLOCK + threadIdx.x;
+    if (n >= n_alive) return;
+    const int index = rays_alive[n];
+    const RmCfg c = rm_cfg(bound, dt_gamma, max_steps, C, H, grid);
+    const RmRay r = rm_load_ray(rays_o, rays_d, (uint32_t)index);
+    float *pxyz = xyzs + (size_t)n * n_step * 3;
+    float *pdir = dirs ? dirs + (size_t)n * n_step * 3 : nullptr;
+    float *pdel = deltas + (size_t)n * n_step * 4;
+    float t = rays_t[(size_t)index * (is_ndc ? 2 : 1)];
+    const float far = fars[index];
+    {
+#pragma clang fp contract(off)
+        const float noise = noises ? noises[n] : 0.0f;
+        t += rm_clamp(t * dt_gamma, c.dt_min, c.dt_max) * noise;   // :1053
+    }
+    uint32_t step = 0;
+    float last_t = t;
+    float last_z = rm_clamp(r.oz + t * r.dz, -bound, bound);
+    float x, y, z, dt, tt;
+    while (t < far && step < n_step) {
+        if (rm_probe(r, c, t, x, y, z, dt, tt)) {
+#pragma clang fp contract(off)
+            pxyz[0] = x; pxyz[1] = y; pxyz[2] = z;
+            if (pdir) { pdir[0] = r.dx; pdir[1] = r.dy; pdir[2] = r.dz; pdir += 3; }
+            t += dt;
+            pdel[0] = dt;
+            pdel[1] = t - last_t;
+            if (is_ndc) {
+                const float new_z = rm_clamp(r.oz + t * r.dz, -bound, bound);
+                const float zh = z_hats[index];
+                pdel[2] = (2 / (new_z - 1) - 2 / (z - 1)) / zh;
+                pdel[3] = (2 / (new_z - 1) - 2 / (last_z - 1)) / zh;
+                last_z = new_z;
+            }
+            last_t = t;
+            pxyz += 3; pdel += 4;
+            step++;
+        } else {
+            rm_skip(c, t, tt);
+        }
+    }
+    // The reference relies on the caller zero-filling deltas (raymarching.py:409-412) so that an
+    // unused tail reads delta == 0 (= "ray terminated", :1178).  Write the terminator here so the
+    // caller does not have to memset [n_alive*n_step, 4] floats per iteration.
+    for (; step < n_step; step++) {
+        pdel[0] = 0.0f;
+        pdel += 4;
+    }
+}
+
+__global__ void __launch_bounds__(RM_BLOCK)
+k_composite_rays(uint32_t n_alive, uint32_t n_step, float T_thresh, int32_t *__restrict__ rays_alive,
+                 float *__restrict__ rays_t, const float *__restrict__ sigmas, const float *__restrict__ rgbs,
+                 const float *__restrict__ deltas, uint32_t C, int is_ndc, float *__restrict__ weights_sum,
+                 float *__restrict__ depth, float *__restrict__ image) {
+    const uint32_t n = blockIdx.x * RM_BLOCK + threadIdx.x;
+    if (n >= n_alive) return;
+    const int index = rays_alive[n];
+    const float *s = sigmas + (size_t)n * n_step;
+    const float *rgb = rgbs + (size_t)n * n_step * C;
+    const float *dl = deltas + (size_t)n * n_step * 4;
+    float *rt = rays_t + (size_t)index * (is_ndc ? 2 : 1);
+    float *img = image + (size_t)index * C;
+    float t_rm = 0.0f, t_phy;
+    if (is_ndc) { t_rm = rt[0]; t_phy = rt[1]; } else { t_phy = rt[0]; }
+    float weight_sum = weights_sum[index];
+    float d = depth[index];
+    float acc[RM_MAXC];
+#pragma unroll
+    for (int i = 0; i < RM_MAXC; i++) acc[i] = (uint32_t)i < C ? img[i] : 0.0f;
+    uint32_t step = 0;
+    while (step < n_step) {
+        if (dl[0] == 0) break;   // :1178
+        const float alpha = 1.0f - __expf(-s[0] * (is_ndc ? dl[2] : dl[0]));
+        const float T = 1 - weight_sum;
+        const float weight = alpha * T;
+        weight_sum += weight;
+        if (is_ndc) { t_rm += dl[1]; t_phy += dl[3]; } else { t_phy += dl[1]; }
+        d += weight * t_phy;
+#pragma unroll
+        for (int i = 0; i < RM_MAXC; i++)
+            if ((uint32_t)i < C) acc[i] += weight * rgb[i];
+        if (T < T_thresh) break;   // :1206
+        s++; rgb += C; dl += 4; step++;
+    }
+    if (step < n_step) {
+        rays_alive[n] = -1;
+    } else {
+        if (is_ndc) { rt[0] = t_rm; rt[1] = t_phy; } else { rt[0] = t_phy; }
+    }
+    weights_sum[index] = weight_sum;
+    depth[index] = d;
+#pragma unroll
+    for (int i = 0; i < RM_MAXC; i++)
+        if ((uint32_t)i < C) img[i] = acc[i];
+}
+
+// ---------------------------------------------------------------------------------------------
+// alive-ray compaction (replaces rays_alive[rays_alive >= 0], renderer.py:284)
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(RM_BLOCK)
+k_alive_count(const int32_t *__restrict__ rays_alive, uint32_t n_alive, uint32_t *__restrict__ block_sums) {
+    __shared__ uint32_t wave_sums[RM_BLOCK / 64];
+    const uint32_t n = blockIdx.x * RM_BLOCK + threadIdx.x;
+    const uint32_t keep = (n < n_alive && rays_alive[n] >= 0) ? 1u : 0u;
+    // one ballot per wave instead of a shuffle scan: popcount of the 64-bit mask
+    const unsigned long long mask = __ballot(keep);
+    if ((threadIdx.x & 63u) == 0) wave_sums[threadIdx.x >> 6] = (uint32_t)__popcll(mask);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t t = 0;
+        for (uint32_t w = 0; w < RM_BLOCK / 64; w++) t += wave_sums[w];
+        block_sums[blockIdx.x] = t;
+    }
+}
+
+__global__ void __launch_bounds__(RM_BLOCK)
+k_alive_write(const int32_t *__restrict__ rays_alive, uint32_t n_alive, const uint32_t *__restrict__ block_bases,
+              int32_t *__restrict__ out) {
+    __shared__ uint32_t wave_sums[RM_BLOCK / 64];
+    const uint32_t n = blockIdx.x * RM_BLOCK + threadIdx.x;
+    const int32_t v = n < n_alive ? rays_alive[n] : -1;
+    const bool keep = v >= 0;
+    const unsigned long long mask = __ballot(keep);
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    if (lane == 0) wave_sums[wave] = (uint32_t)__popcll(mask);
+    __syncthreads();
+    uint32_t base = block_bases[blockIdx.x];
+    for (uint32_t w = 0; w < wave; w++) base += wave_sums[w];
+    if (keep) out[base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = v;
+}
+
+__global__ void k_store_scan_total(const int32_t *__restrict__ counter2, int32_t *__restrict__ n_out) {
+    n_out[0] = counter2[0];
+}
+
+// ---------------------------------------------------------------------------------------------
+// device ray generation (nerf_lib.py:69-142, common.py:139-147)
+// ---------------------------------------------------------------------------------------------
+__global__ void k_generate_rays(const float *__restrict__ pose, uint32_t w, uint32_t h, float fx, float fy, float cx,
+                                float cy, int camera_flip, const int32_t *__restrict__ pix, uint32_t N,
+                                float *__restrict__ rays_o, float *__restrict__ rays_d) {
+#pragma clang fp contract(off)
+    const float r00 = pose[0], r01 = pose[1], r02 = pose[2], tx = pose[3];
+    const float r10 = pose[4], r11 = pose[5], r12 = pose[6], ty = pose[7];
+    const float r20 = pose[8], r21 = pose[9], r22 = pose[10], tz = pose[11];
+    const float f0 = (camera_flip >> 2) & 1 ? -1.0f : 1.0f;   // nerf_lib.py:121, bit order [2,1,0]
+    const float f1 = (camera_flip >> 1) & 1 ? -1.0f : 1.0f;
+    const float f2 = (camera_flip >> 0) & 1 ? -1.0f : 1.0f;
+    for (uint32_t n = blockIdx.x * blockDim.x + threadIdx.x; n < N; n += gridDim.x * blockDim.x) {
+        const uint32_t p = pix ? (uint32_t)pix[n] : n;
+        const uint32_t py = p / w, px = p - py * w;
+        // np.linspace(0, w, 2w+1)[1::2] == x + 0.5 exactly in fp32 for w < 2^22
+        const float i = (float)px + 0.5f, j = (float)py + 0.5f;
+        const float d0 = ((i - cx) / fx) * f0, d1 = ((j - cy) / fy) * f1, d2 = f2;
+        const float wx = r00 * d0 + r01 * d1 + r02 * d2;
+        const float wy = r10 * d0 + r11 * d1 + r12 * d2;
+        const float wz = r20 * d0 + r21 * d1 + r22 * d2;
+        const float nrm = sqrtf(wx * wx + wy * wy + wz * wz);
+        rays_d[n * 3 + 0] = wx / nrm; rays_d[n * 3 + 1] = wy / nrm; rays_d[n * 3 + 2] = wz / nrm;
+        rays_o[n * 3 + 0] = tx; rays_o[n * 3 + 1] = ty; rays_o[n * 3 + 2] = tz;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------
+extern "C" {
+
+const char *nsr_status_string(int status) {
+    switch (status) {
+        case NSR_OK: return "ok";
+        case NSR_ERR_INVALID_ARG: return "invalid argument (null pointer, bad size or enum)";
+        case NSR_ERR_UNSUPPORTED: return "unsupported configuration for the gfx950 kernels";
+        case NSR_ERR_LAUNCH: return "HIP kernel launch failed";
+        default: return "unknown status";
+    }
+}
+int nsr_abi_version(void) { return 1; }
+const char *nsr_target_arch(void) { return "gfx950"; }
+
+int nsr_near_far_from_aabb(const float *rays_o, const float *rays_d, const float *aabb, uint32_t N, float min_near,
+                           float *nears, float *fars, nsr_stream_t stream) {
+    if (N == 0) return NSR_OK;
+    NSR_CHECK_PTR(rays_o); NSR_CHECK_PTR(rays_d); NSR_CHECK_PTR(aabb); NSR_CHECK_PTR(nears); NSR_CHECK_PTR(fars);
+    hipLaunchKernelGGL(k_near_far_from_aabb, dim3(nsr_grid_1d(N, 256)), dim3(256), 0, (hipStream_t)stream, rays_o, rays_d,
+                       aabb, N, min_near, nears, fars);
+    return nsr_launch_status();
+}
+
+int nsr_morton3d(const int32_t *coords, uint32_t N, int32_t *indices, nsr_stream_t stream) {
+    if (N == 0) return NSR_OK;
+    NSR_CHECK_PTR(coords); NSR_CHECK_PTR(indices);
+    hipLaunchKernelGGL(k_morton3d, dim3(nsr_grid_1d(N, 256)), dim3(256), 0, (hipStream_t)stream, coords, N, indices);
+    return nsr_launch_status();
+}
+
+int nsr_morton3d_invert(const int32_t *indices, uint32_t N, int32_t *coords, nsr_stream_t stream) {
+    if (N == 0) return NSR_OK;
+    NSR_CHECK_PTR(coords); NSR_CHECK_PTR(indices);
+    hipLaunchKernelGGL(k_morton3d_invert, dim3(nsr_grid_1d(N, 256)), dim3(256), 0, (hipStream_t)stream, indices, N, coords);
+    return nsr_launch_status();
+}
+
+int nsr_packbits(const float *grid, uint32_t N, float density_thresh, uint8_t *bitfield, nsr_stream_t stream) {
+    if (N == 0) return NSR_OK;
+    NSR_CHECK_PTR(grid); NSR_CHECK_PTR(bitfield);
+    if (((uintptr_t)grid & 15u) != 0) return NSR_ERR_INVALID_ARG;   // 16-byte loads
+    hipLaunchKernelGGL(k_packbits, dim3(nsr_grid_1d(N, 256)), dim3(256), 0, (hipStream_t)stream, grid, N, density_thresh,
+                       bitfield);
+    return nsr_launch_status();
+}
+
+uint64_t nsr_march_rays_train_workspace_bytes(uint32_t N) {
+    const uint64_t nblocks = (N + RM_BLOCK - 1) / RM_BLOCK;
+    return ((uint64_t)N + nblocks + 64) * sizeof(uint32_t);
+}
+
+int nsr_march_rays_train(const float *rays_o, const float *rays_d, const float *z_hats, const uint8_t *grid, float bound,
+                         float dt_gamma, uint32_t max_steps, int is_ndc, uint32_t N, uint32_t C, uint32_t H, uint32_t M,
+                         const float *nears, const float *fars, float *xyzs, float *dirs, float *deltas, int32_t *rays,
+                         int32_t *counter, const float *noises, void *workspace, nsr_stream_t stream) {
+    if (N == 0) return NSR_OK;
+    NSR_CHECK_PTR(rays_o); NSR_CHECK_PTR(rays_d); NSR_CHECK_PTR(grid); NSR_CHECK_PTR(nears); NSR_CHECK_PTR(fars);
+    NSR_CHECK_PTR(xyzs); NSR_CHECK_PTR(deltas); NSR_CHECK_PTR(rays); NSR_CHECK_PTR(counter); NSR_CHECK_PTR(workspace);
+    if (is_ndc && z_hats == nullptr) return NSR_ERR_INVALID_ARG;
+    if (max_steps == 0 || C == 0 || C > 8 || H == 0 || H > 1024) return NSR_ERR_INVALID_ARG;
+    if (((uintptr_t)deltas & 15u) != 0) return NSR_ERR_INVALID_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    const uint32_t nblocks = (N + RM_BLOCK - 1) / RM_BLOCK;
+    uint32_t *counts = (uint32_t *)workspace;
+    uint32_t *block_sums = counts + N;
+    hipLaunchKernelGGL(k_march_count, dim3(nblocks), dim3(RM_BLOCK), 0, s, rays_o, rays_d, grid, bound, dt_gamma, max_steps, N,
+                       C, H, nears, fars, noises, counts, block_sums);
+    // the reference's ray slots start at the incoming counter[1]; only 0 is supported without a
+    // host read (renderer.py:213-214 zeroes the counter before every call)
+    hipLaunchKernelGGL(k_scan_block_sums, dim3(1), dim3(1024), 0, s, block_sums, nblocks, counter, N);
+    hipLaunchKernelGGL(k_march_emit, dim3(nblocks), dim3(RM_BLOCK), 0, s, rays_o, rays_d, z_hats, grid, bound, dt_gamma,
+                       max_steps, is_ndc, N, C, H, M, nears, fars, noises, counts, block_sums, 0u, xyzs, dirs, deltas, rays);
+    return nsr_launch_status();
+}
+
+int nsr_composite_rays_train_forward(const float *sigmas, const float *rgbs, const float *deltas, const int32_t *rays,
+                                     uint32_t M, uint32_t N, uint32_t C, float T_thresh, int is_ndc, float *weights_sum,
+                                     float *depth, float *image, nsr_stream_t stream) {
+    if (N == 0) return NSR_OK;
+    NSR_CHECK_PTR(sigmas); NSR_CHECK_PTR(rgbs); NSR_CHECK_PTR(deltas); NSR_CHECK_PTR(rays);
+    NSR_CHECK_PTR(weights_sum); NSR_CHECK_PTR(depth); NSR_CHECK_PTR(image);
+    if (C == 0 || C > RM_MAXC) return NSR_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(k_composite_train_fwd, dim3(nsr_div_up(N, RM_BLOCK)), dim3(RM_BLOCK), 0, (hipStream_t)stream, sigmas,
+                       rgbs, deltas, rays, M, N, C, T_thresh, is_ndc, weights_sum, depth, image);
+    return nsr_launch_status();
+}
+
+int nsr_composite_rays_train_backward(const float *grad_weights_sum, const float *grad_image, const float *sigmas,
+                                      const float *rgbs, const float *deltas, const int32_t *rays, int is_ndc,
+                                      const float *weights_sum, const float *image, uint32_t M, uint32_t N, uint32_t C,
+                                      float T_thresh, float *grad_sigmas, float *grad_rgbs, nsr_stream_t stream) {
+    if (N == 0) return NSR_OK;
+    NSR_CHECK_PTR(grad_weights_sum); NSR_CHECK_PTR(grad_image); NSR_CHECK_PTR(sigmas); NSR_CHECK_PTR(rgbs);
+    NSR_CHECK_PTR(deltas); NSR_CHECK_PTR(rays); NSR_CHECK_PTR(weights_sum); NSR_CHECK_PTR(image);
+    NSR_CHECK_PTR(grad_sigmas); NSR_CHECK_PTR(grad_rgbs);
+    if (C == 0 || C > RM_MAXC) return NSR_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(k_composite_train_bwd, dim3(nsr_div_up(N, RM_BLOCK)), dim3(RM_BLOCK), 0, (hipStream_t)stream,
+                       grad_weights_sum, grad_image, sigmas, rgbs, deltas, rays, is_ndc, weights_sum, image, M, N, C, T_thresh,
+                       grad_sigmas, grad_rgbs);
+    return nsr_launch_status();
+}
+
+int nsr_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t *rays_alive, const float *rays_t, const float *rays_o,
+                   const float *rays_d, const float *z_hats, float bound, float dt_gamma, uint32_t max_steps, int is_ndc,
+                   uint32_t C, uint32_t H, const uint8_t *grid, const float *nears, const float *fars, float *xyzs,
+                   float *dirs, float *deltas, const float *noises, nsr_stream_t stream) {
+    if (n_alive == 0 || n_step == 0) return NSR_OK;
+    NSR_CHECK_PTR(rays_alive); NSR_CHECK_PTR(rays_t); NSR_CHECK_PTR(rays_o); NSR_CHECK_PTR(rays_d); NSR_CHECK_PTR(grid);
+    NSR_CHECK_PTR(fars); NSR_CHECK_PTR(xyzs); NSR_CHECK_PTR(deltas);
+    (void)nears;
+    if (is_ndc && z_hats == nullptr) return NSR_ERR_INVALID_ARG;
+    if (max_steps == 0 || C == 0 || C > 8 || H == 0 || H > 1024) return NSR_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(k_march_rays, dim3(nsr_div_up(n_alive, RM_BLOCK)), dim3(RM_BLOCK), 0, (hipStream_t)stream, n_alive,
+                       n_step, rays_alive, rays_t, rays_o, rays_d, z_hats, bound, dt_gamma, max_steps, is_ndc, C, H, grid, fars,
+                       xyzs, dirs, deltas, noises);
+    return nsr_launch_status();
+}
+
+int nsr_composite_rays(uint32_t n_alive, uint32_t n_step, float T_thresh, int32_t *rays_alive, float *rays_t,
+                       const float *sigmas, const float *rgbs, const float *deltas, uint32_t C, int is_ndc,
+                       float *weights_sum, float *depth, float *image, nsr_stream_t stream) {
+    if (n_alive == 0 || n_step == 0) return NSR_OK;
+    NSR_CHECK_PTR(rays_alive); NSR_CHECK_PTR(rays_t); NSR_CHECK_PTR(sigmas); NSR_CHECK_PTR(rgbs); NSR_CHECK_PTR(deltas);
+    NSR_CHECK_PTR(weights_sum); NSR_CHECK_PTR(depth); NSR_CHECK_PTR(image);
+    if (C == 0 || C > RM_MAXC) return NSR_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(k_composite_rays, dim3(nsr_div_up(n_alive, RM_BLOCK)), dim3(RM_BLOCK), 0, (hipStream_t)stream, n_alive,
+                       n_step, T_thresh, rays_alive, rays_t, sigmas, rgbs, deltas, C, is_ndc, weights_sum, depth, image);
+    return nsr_launch_status();
+}
+
+uint64_t nsr_compact_alive_workspace_bytes(uint32_t n_alive) {
+    const uint64_t nblocks = (n_alive + RM_BLOCK - 1) / RM_BLOCK;
+    return (nblocks + 64) * sizeof(uint32_t);
+}
+
+int nsr_compact_alive(const int32_t *rays_alive, uint32_t n_alive, int32_t *out, int32_t *n_out, void *workspace,
+                      nsr_stream_t stream) {
+    NSR_CHECK_PTR(n_out);
+    hipStream_t s = (hipStream_t)stream;
+    if (n_alive == 0) {
+        return hipMemsetAsync(n_out, 0, sizeof(int32_t), s) == hipSuccess ? NSR_OK : NSR_ERR_LAUNCH;
+    }
+    NSR_CHECK_PTR(rays_alive); NSR_CHECK_PTR(out); NSR_CHECK_PTR(workspace);
+    const uint32_t nblocks = (n_alive + RM_BLOCK - 1) / RM_BLOCK;
+    uint32_t *block_sums = (uint32_t *)workspace;
+    int32_t *counter2 = (int32_t *)(block_sums + nblocks);   // scratch {total, unused}
+    if (hipMemsetAsync(counter2, 0, 2 * sizeof(int32_t), s) != hipSuccess) return NSR_ERR_LAUNCH;
+    hipLaunchKernelGGL(k_alive_count, dim3(nblocks), dim3(RM_BLOCK), 0, s, rays_alive, n_alive, block_sums);
+    hipLaunchKernelGGL(k_scan_block_sums, dim3(1), dim3(1024), 0, s, block_sums, nblocks, counter2, 0u);
+    hipLaunchKernelGGL(k_alive_write, dim3(nblocks), dim3(RM_BLOCK), 0, s, rays_alive, n_alive, block_sums, out);
+    hipLaunchKernelGGL(k_store_scan_total, dim3(1), dim3(1), 0, s, counter2, n_out);
+    return nsr_launch_status();
+}
+
+int nsr_generate_rays(const float *pose, uint32_t w, uint32_t h, float fx, float fy, float cx, float cy, int camera_flip,
+                      const int32_t *pix, uint32_t N, float *rays_o, float *rays_d, nsr_stream_t stream) {
+    if (N == 0) return NSR_OK;
+    NSR_CHECK_PTR(pose); NSR_CHECK_PTR(rays_o); NSR_CHECK_PTR(rays_d);
+    if (w == 0 || h == 0) return NSR_ERR_INVALID_ARG;
+    if (pix == nullptr && (uint64_t)N != (uint64_t)w * h) return NSR_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(k_generate_rays, dim3(nsr_grid_1d(N, 256)), dim3(256), 0, (hipStream_t)stream, pose, w, h, fx, fy, cx, cy,
+                       camera_flip, pix, N, rays_o, rays_d);
+    return nsr_launch_status();
+}
+
+}   // extern "C"
