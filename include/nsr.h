@@ -104,8 +104,9 @@ int nsr_composite_rays_train_forward(const float *sigmas, const float *rgbs, con
 /* replaces composite_rays_train_backward (raymarching.h:15, raymarching.cu:904-997).
  * The reference needs grad_sigmas, grad_rgbs pre-zeroed and an [N,C] scratch rgbs_buf
  * (raymarching.py:339-341); here the running colour sum lives in registers, rgbs_buf is gone,
- * and entries of grad_sigmas / grad_rgbs the reference leaves at zero are written as zero
- * only inside live rays -- callers still pass zero-filled buffers for dropped rays and padding. */
+ * and every sample that belongs to a ray (early-stopped tails and dropped rays included) gets its
+ * gradient written -- zeros where the reference leaves the pre-filled zero -- so the buffers need
+ * NOT arrive zeroed; only padding samples that belong to no ray are left untouched. */
 int nsr_composite_rays_train_backward(const float *grad_weights_sum, const float *grad_image,
                                       const float *sigmas, const float *rgbs, const float *deltas,
                                       const int32_t *rays, int is_ndc, const float *weights_sum,
@@ -233,10 +234,14 @@ int nsr_cast_f32_to_f16(const float *src, void *dst, uint64_t n, nsr_stream_t st
 /* Fused Adam (+ optional EMA shadow) over a flat fp32 arena, one pass, grads zeroed on the way
  * out (replaces torch.optim.Adam + zero_grad + torch_ema, trainers/base.py:216-229,420-426).
  * grad_scale_inv multiplies the gradient first (GradScaler unscale). step >= 1.
- * half_copy (f16, may be NULL) receives the updated parameters rounded to half. */
+ * half_copy (f16, may be NULL) receives the updated parameters rounded to half.
+ * elem_mask4: bit (i & 3) set <=> element i is trained; others keep parameter and moments (their
+ * gradient is still zeroed).  0xF = everything; on the interleaved tables 0x3 = density table only,
+ * 0xC = colour table only (stylisation, trainers/style.py:25). */
 int nsr_adam_step(float *params, float *grads, float *exp_avg, float *exp_avg_sq, float *ema,
                   void *half_copy, uint64_t n, float lr, float beta1, float beta2, float eps,
-                  float grad_scale_inv, float ema_decay, uint32_t step, nsr_stream_t stream);
+                  float grad_scale_inv, float ema_decay, uint32_t step, uint32_t elem_mask4,
+                  nsr_stream_t stream);
 
 /* Ray generation on the device (nerf_lib.py:69-142 + common.py:139-147): pixel centres
  * (x + 0.5), camera-frame direction ((i-cx)/fx, (j-cy)/fy, 1) * flip, R * d, normalise.

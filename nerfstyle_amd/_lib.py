@@ -65,7 +65,7 @@ SIGNATURES = {
     'nsr_field_forward': (i32, [ctypes.POINTER(FieldDesc), vp, vp, vp, u32, vp, vp, vp, vp]),
     'nsr_field_backward': (i32, [ctypes.POINTER(FieldDesc), vp, vp, vp, u32, vp, vp, vp, vp, vp, i32, i32, vp]),
     'nsr_cast_f32_to_f16': (i32, [vp, vp, u64, vp]),
-    'nsr_adam_step': (i32, [vp, vp, vp, vp, vp, vp, u64, f32, f32, f32, f32, f32, f32, u32, vp]),
+    'nsr_adam_step': (i32, [vp, vp, vp, vp, vp, vp, u64, f32, f32, f32, f32, f32, f32, u32, u32, vp]),
     'nsr_generate_rays': (i32, [vp, u32, u32, f32, f32, f32, f32, i32, vp, u32, vp, vp, vp]),
 }
 

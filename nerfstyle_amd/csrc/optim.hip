@@ -9,6 +9,7 @@ struct AdamArgs {
     _Float16 *half_copy;
     uint64_t n;
     float beta1, beta2, eps, step_size, inv_sqrt_bc2, grad_scale_inv, ema_decay;
+    uint32_t mask4;
 };
 
 __device__ __forceinline__ float adam_one(float &p, float g, float &m, float &v, const AdamArgs &a) {
@@ -28,10 +29,10 @@ k_adam(AdamArgs a) {
         const float4 g = reinterpret_cast<float4 *>(a.g)[i];
         float4 m = reinterpret_cast<float4 *>(a.m)[i];
         float4 v = reinterpret_cast<float4 *>(a.v)[i];
-        adam_one(p.x, g.x, m.x, v.x, a);
-        adam_one(p.y, g.y, m.y, v.y, a);
-        adam_one(p.z, g.z, m.z, v.z, a);
-        adam_one(p.w, g.w, m.w, v.w, a);
+        if (a.mask4 & 1u) adam_one(p.x, g.x, m.x, v.x, a);
+        if (a.mask4 & 2u) adam_one(p.y, g.y, m.y, v.y, a);
+        if (a.mask4 & 4u) adam_one(p.z, g.z, m.z, v.z, a);
+        if (a.mask4 & 8u) adam_one(p.w, g.w, m.w, v.w, a);
         reinterpret_cast<float4 *>(a.p)[i] = p;
         reinterpret_cast<float4 *>(a.m)[i] = m;
         reinterpret_cast<float4 *>(a.v)[i] = v;
@@ -52,7 +53,7 @@ k_adam(AdamArgs a) {
     if (blockIdx.x == 0 && threadIdx.x < (a.n & 3u)) {
         const uint64_t i = n4 * 4 + threadIdx.x;
         float p = a.p[i], m = a.m[i], v = a.v[i];
-        adam_one(p, a.g[i], m, v, a);
+        if (a.mask4 & (1u << (i & 3u))) adam_one(p, a.g[i], m, v, a);
         a.p[i] = p; a.m[i] = m; a.v[i] = v; a.g[i] = 0.0f;
         if (a.ema) a.ema[i] -= (1.0f - a.ema_decay) * (a.ema[i] - p);
         if (a.half_copy) a.half_copy[i] = (_Float16)p;
@@ -61,7 +62,7 @@ k_adam(AdamArgs a) {
 
 extern "C" int nsr_adam_step(float *params, float *grads, float *exp_avg, float *exp_avg_sq, float *ema, void *half_copy,
                              uint64_t n, float lr, float beta1, float beta2, float eps, float grad_scale_inv, float ema_decay,
-                             uint32_t step, nsr_stream_t stream) {
+                             uint32_t step, uint32_t elem_mask4, nsr_stream_t stream) {
     if (n == 0) return NSR_OK;
     NSR_CHECK_PTR(params); NSR_CHECK_PTR(grads); NSR_CHECK_PTR(exp_avg); NSR_CHECK_PTR(exp_avg_sq);
     if (step == 0) return NSR_ERR_INVALID_ARG;
@@ -70,6 +71,7 @@ extern "C" int nsr_adam_step(float *params, float *grads, float *exp_avg, float 
     if (al & 15u) return NSR_ERR_INVALID_ARG;
     AdamArgs a;
     a.p = params; a.g = grads; a.m = exp_avg; a.v = exp_avg_sq; a.ema = ema; a.half_copy = (_Float16 *)half_copy; a.n = n;
+    a.mask4 = elem_mask4 & 0xFu;
     a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.grad_scale_inv = grad_scale_inv; a.ema_decay = ema_decay;
     const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
     a.step_size = (float)((double)lr / bc1);

@@ -371,11 +371,22 @@ k_composite_train_bwd(const float *__restrict__ grad_weights_sum, const float *_
                       const float *__restrict__ sigmas, const float *__restrict__ rgbs, const float *__restrict__ deltas,
                       const int32_t *__restrict__ rays, int is_ndc, const float *__restrict__ weights_sum,
                       const float *__restrict__ image, uint32_t M, uint32_t N, uint32_t C, float T_thresh,
-                      float *__restrict__ grad_sigmas, float *__restrict__ grad_rgbs) {
+                      float *__restrict__ grad_sigmas, float *__restrict__ grad_rgbs, int zero_fill) {
     const uint32_t n = blockIdx.x * RM_BLOCK + threadIdx.x;
     if (n >= N) return;
     const uint32_t index = (uint32_t)rays[n * 3], offset = (uint32_t)rays[n * 3 + 1], num_steps = (uint32_t)rays[n * 3 + 2];
-    if (num_steps == 0 || offset + num_steps >= M) return;
+    if (num_steps == 0) return;
+    if (offset + num_steps >= M) {
+        // dropped ray (:929): the reference leaves its pre-zeroed gradients untouched; write the
+        // zeros here (inside the buffer only) so that callers need no memset of [M, 1 + C]
+        if (zero_fill) {
+            for (uint32_t step = 0; step < num_steps && offset + step < M; step++) {
+                grad_sigmas[offset + step] = 0.0f;
+                for (uint32_t i = 0; i < C; i++) grad_rgbs[(size_t)(offset + step) * C + i] = 0.0f;
+            }
+        }
+        return;
+    }
     float buf[RM_MAXC], gim[RM_MAXC], im[RM_MAXC];
 #pragma unroll
     for (int i = 0; i < RM_MAXC; i++) {
@@ -391,7 +402,8 @@ k_composite_train_bwd(const float *__restrict__ grad_weights_sum, const float *_
     float *gs = grad_sigmas + offset;
     float *grgb = grad_rgbs + (size_t)offset * C;
     float T = 1.0f;
-    for (uint32_t step = 0; step < num_steps; step++) {
+    uint32_t step = 0;
+    for (; step < num_steps; step++) {
         const float delta = is_ndc ? dl[step * 4 + 2] : dl[step * 4 + 0];
         const float alpha = 1.0f - __expf(-s[step] * delta);
         const float weight = alpha * T;
@@ -412,6 +424,13 @@ k_composite_train_bwd(const float *__restrict__ grad_weights_sum, const float *_
             }
         }
         gs[step] = delta * (gsum + gws * (1 - ws_final));
+    }
+    // samples at and after the early stop keep the zero gradient the reference pre-fills
+    if (zero_fill) {
+        for (; step < num_steps; step++) {
+            gs[step] = 0.0f;
+            for (uint32_t i = 0; i < C; i++) grgb[(size_t)step * C + i] = 0.0f;
+        }
     }
 }
 
@@ -689,7 +708,7 @@ int nsr_composite_rays_train_backward(const float *grad_weights_sum, const float
     if (C == 0 || C > RM_MAXC) return NSR_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(k_composite_train_bwd, dim3(nsr_div_up(N, RM_BLOCK)), dim3(RM_BLOCK), 0, (hipStream_t)stream,
                        grad_weights_sum, grad_image, sigmas, rgbs, deltas, rays, is_ndc, weights_sum, image, M, N, C, T_thresh,
-                       grad_sigmas, grad_rgbs);
+                       grad_sigmas, grad_rgbs, 1);
     return nsr_launch_status();
 }
 

@@ -1,0 +1,94 @@
+"""Multi-GPU data parallelism over rays: one process per GPU, every rank
+holds a full replica of the parameter arena, the occupancy bitfield and the optimiser state, the
+ray batch is split across ranks, and ONE RCCL all-reduce (sum) of the flat gradient arena per
+optimiser step keeps the replicas identical.  The reference has no distributed code at all
+(device hard-coded to cuda:0, trainers/base.py:119); this is the only collective the path needs.
+
+xGMI is point-to-point (7 links per GPU): a single large message lets RCCL drive all links, so
+the gradient is reduced as one flat bucket (25.2 M fp32 = 100.9 MB; stylisation 50.4 MB), not per
+tensor.  Loss terms are divided by the world size before backward so the summed gradient equals
+the single-GPU gradient of the global batch.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def env_world():
+    return int(os.environ.get('RANK', 0)), int(os.environ.get('LOCAL_RANK', 0)), int(os.environ.get('WORLD_SIZE', 1))
+
+
+def init(backend=None):
+    """Initialises torch.distributed from the torchrun environment (no-op for one process).
+    backend: 'nccl' (= RCCL on ROCm) when CUDA/HIP is available, else 'gloo'."""
+    rank, local_rank, world = env_world()
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29500')
+        if backend == 'nccl':
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local_rank, world
+
+
+def world_size():
+    return dist.get_world_size() if dist.is_initialized() else 1
+
+
+def shard_bounds(n, rank, world):
+    """Contiguous, balanced [begin, end) split of n units (rays / pixel rows / patches)."""
+    base, rem = divmod(n, world)
+    begin = rank * base + min(rank, rem)
+    return begin, begin + base + (1 if rank < rem else 0)
+
+
+def rank_generator(seed, rank, device='cpu'):
+    """Rank-distinct RNG stream for pixel sampling (rank-identical streams, e.g. for the occupancy
+    jitter, simply use `seed` on every rank)."""
+    g = torch.Generator(device=device)
+    g.manual_seed(int(seed) * 1000003 + int(rank))
+    return g
+
+
+def all_reduce_sum_(flat: torch.Tensor, max_bucket_bytes=None):
+    """In-place sum over ranks of one flat tensor; optionally in buckets of max_bucket_bytes so
+    that an optimiser pass over an already-reduced bucket can overlap the next bucket."""
+    if world_size() == 1:
+        return flat
+    if max_bucket_bytes is None or flat.numel() * flat.element_size() <= max_bucket_bytes:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        return flat
+    per = max(1, max_bucket_bytes // flat.element_size())
+    works = [dist.all_reduce(flat[i:i + per], op=dist.ReduceOp.SUM, async_op=True) for i in range(0, flat.numel(), per)]
+    for w in works:
+        w.wait()
+    return flat
+
+
+def broadcast_(flat: torch.Tensor, src=0):
+    if world_size() > 1:
+        dist.broadcast(flat, src=src)
+    return flat
+
+
+def sync_gradients(model, only_color_table=False):
+    """All-reduce of the gradient arena.  Stylisation trains the colour table only
+    (trainers/style.py:25); the interleaved layout keeps both tables in one message either way."""
+    g = model._ensure_grad()
+    return all_reduce_sum_(g)
+
+
+def barrier():
+    if world_size() > 1:
+        dist.barrier()
+
+
+def max_over_ranks(value: float, device) -> float:
+    if world_size() == 1:
+        return value
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())

@@ -1,0 +1,59 @@
+"""Ray generation: counterpart of nerf_lib.generate_rays (nerf_lib.py:69-142) + RayBatch's
+normalisation (common.py:139-147), done by one device kernel (nsr_generate_rays) instead of a
+NumPy meshgrid + H2D copy + einsum per call."""
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from .common import Box2D, Intrinsics, RayBatch
+
+
+def pixel_ids(intr: Intrinsics, patch: Optional[Box2D] = None, precrop: float = 1., device=None):
+    """Row-major pixel ids (y * W + x) of the full frame / centre crop / patch, as the reference
+    slices x_coords / y_coords (nerf_lib.py:106-113).  Returns (ids int32 [w*h], w, h, dx, dy)."""
+    assert 0. <= precrop <= 1.
+    assert precrop >= 1. or patch is None, 'Using both precrop and patch is not supported'
+    W, H = intr.size()
+    w, h, dx, dy = W, H, 0, 0
+    if precrop < 1.:
+        w, h = int(W * precrop), int(H * precrop)
+        dx, dy = (W - w) // 2, (H - h) // 2
+    if patch is not None:
+        dx, dy, w, h = patch.x, patch.y, min(patch.w, W - patch.x), min(patch.h, H - patch.y)
+    ys = torch.arange(dy, dy + h, device=device, dtype=torch.int32)
+    xs = torch.arange(dx, dx + w, device=device, dtype=torch.int32)
+    ids = (ys[:, None] * W + xs[None, :]).reshape(-1)
+    return ids, w, h, dx, dy
+
+
+def generate_rays(pose, intr: Intrinsics, img=None, patch: Optional[Box2D] = None, precrop: float = 1.,
+                  bsize: Optional[int] = None, camera_flip: int = 0, pix_subset=None, device=None):
+    """Same arguments and returns as the reference (RayBatch, target).  bsize: that many pixels
+    drawn without replacement with np.random.choice, exactly like nerf_lib.py:134 (pass
+    `pix_subset`, positions into the cropped pixel list, to supply your own / device-side draw).
+    img: [C, H, W] tensor -> target [K, C]."""
+    device = device or (pose.device if torch.is_tensor(pose) else None)
+    pose = torch.as_tensor(pose, dtype=torch.float32, device=device).contiguous()
+    device = pose.device
+    ids, w, h, dx, dy = pixel_ids(intr, patch, precrop, device)
+    W, H = intr.size()
+    if bsize is not None and pix_subset is None:
+        pix_subset = torch.from_numpy(np.random.choice(np.arange(w * h), bsize, replace=False)).to(device)
+    if pix_subset is not None:
+        ids = ids[pix_subset.long()].contiguous()
+    N = ids.shape[0]
+    rays_o = torch.empty(N, 3, dtype=torch.float32, device=device)
+    rays_d = torch.empty(N, 3, dtype=torch.float32, device=device)
+    L.check(L.lib().nsr_generate_rays(L.p(pose), W, H, float(intr.fx), float(intr.fy), float(intr.cx), float(intr.cy),
+                                      int(camera_flip), L.p(ids), N, L.p(rays_o), L.p(rays_d), L.stream()),
+            'generate_rays')
+    target = None
+    if img is not None:
+        if H != img.shape[-2] or W != img.shape[-1]:
+            img = torch.nn.functional.interpolate(img.unsqueeze(0), size=(H, W)).squeeze(0)
+        target = img.reshape(img.shape[0], -1).t()[ids.long()]
+    rays = RayBatch.__new__(RayBatch)    # directions are already unit length (normalised in-kernel)
+    rays.origins, rays.dirs = rays_o, rays_d
+    return rays, target

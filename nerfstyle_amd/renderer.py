@@ -1,0 +1,265 @@
+"""Host orchestration of the hot path: the counterpart of the reference's renderer.py
+(`Renderer`: update_state :139-194, render_train :196-235, render_test :237-293, render :295-313,
+state_dict / load_state_dict :78-107).  Same public methods, same state keys, same outputs.
+
+What is different underneath (MI355X-first):
+  * render_train never reads the sample count on the host: the march emits into a
+    capacity-bounded buffer, the count stays on the device and the fused field kernels bound
+    themselves by it (the reference does `step_counter[0].item()` + `empty_cache()` per call and
+    memsets 40 B x N x max_steps first, raymarching.py:238-283);
+  * the model is two fused launches (forward / backward), not 2 encoders + 4 MLPs + exp + cat;
+  * the white-background / depth epilogue stays in torch (a few [N]-sized ops).
+"""
+from math import ceil, log2
+from typing import Dict, Optional
+
+import torch
+
+from . import raymarching
+from .common import Box2D, Intrinsics, RayBatch
+from .config import RendererConfig
+from .rays import generate_rays
+from .style_nerf import StyleTCNerf
+
+STEP_CTR_SIZE = 16
+
+
+class Renderer(torch.nn.Module):
+    def __init__(self, model: StyleTCNerf, cfg: RendererConfig, intr: Intrinsics, bound: float, name: str = 'Renderer',
+                 precrop_frac: float = 1., raymarch_channels: int = 3, samples_per_ray_cap: Optional[int] = None):
+        """samples_per_ray_cap: capacity of the sample buffers in samples per ray (None = max_steps,
+        i.e. the reference's force_all_rays allocation N * max_steps; smaller values trade memory for
+        the reference's mean_count-style "drop rays that do not fit" behaviour, raymarching.py:230-236)."""
+        super().__init__()
+        self.model = model
+        self.cfg = cfg
+        self.intr = intr
+        self._use_precrop = False
+        self.precrop_frac = precrop_frac
+        self.raymarch_channels = raymarch_channels
+        self.update_occ = True
+        self.bound = bound
+        self.samples_per_ray_cap = samples_per_ray_cap
+        self.aabb = torch.tensor([-bound, -bound, -bound, bound, bound, bound], dtype=torch.float32)
+        self.cascade = 1 + ceil(log2(bound))
+        grid_size = self.cfg.grid_size
+        bitfield_size = self.cascade * (grid_size ** 3) // 8
+        self.density_grid = torch.zeros((self.cascade, grid_size ** 3))
+        self.density_bitfield = torch.zeros((bitfield_size, ), dtype=torch.uint8)
+        self.step_counter = torch.zeros((STEP_CTR_SIZE, 2), dtype=torch.int32)
+        self.local_step = 0
+        self.mean_count = 0
+        self.mean_density = 0
+        self.device = torch.device('cpu')
+
+    # TensorModule behaviour of the reference (common.py:207-240): plain tensor attributes move too
+    def _apply(self, fn, *args, **kwargs):
+        for k in ('aabb', 'density_grid', 'density_bitfield', 'step_counter'):
+            setattr(self, k, fn(getattr(self, k)))
+        super()._apply(fn, *args, **kwargs)
+        self.device = self.aabb.device
+        return self
+
+    def state_dict(self):
+        """renderer.py:78-91"""
+        sd = {'model': self.model.state_dict()}
+        for k in ['intr', 'precrop_frac', 'raymarch_channels', 'bound', 'density_grid', 'density_bitfield',
+                  'step_counter', 'local_step', 'mean_count', 'mean_density']:
+            v = getattr(self, k)
+            if torch.is_tensor(v):
+                v = v.detach()
+            sd[k] = v
+        return sd
+
+    def load_state_dict(self, state_dict):
+        """renderer.py:93-107"""
+        for k in ['intr', 'precrop_frac', 'raymarch_channels', 'bound']:
+            if getattr(self, k) != state_dict[k]:
+                raise RuntimeError('Values do not match when loading key "{}"'.format(k))
+        self.model.load_state_dict(state_dict['model'])
+        for k in ['density_grid', 'density_bitfield', 'step_counter', 'local_step', 'mean_count', 'mean_density']:
+            v = state_dict[k]
+            if torch.is_tensor(v):
+                v = v.to(self.device)
+            setattr(self, k, v)
+
+    @property
+    def use_precrop(self):
+        return self._use_precrop
+
+    @use_precrop.setter
+    def use_precrop(self, value: bool):
+        self._use_precrop = value
+
+    # ---- occupancy grid ------------------------------------------------------------------------
+    def _compute_occ_sigmas(self, xyzs, cas):
+        """renderer.py:120-136"""
+        bound = min(2 ** cas, self.bound)
+        half_grid_size = bound / self.cfg.grid_size
+        cas_xyzs = xyzs * (bound - half_grid_size)
+        cas_xyzs += (torch.rand_like(cas_xyzs) * 2 - 1) * half_grid_size
+        return self.model.field(cas_xyzs, sigma_only=True, density_scale=self.cfg.density_scale).detach()
+
+    @torch.no_grad()
+    def update_state(self) -> None:
+        """renderer.py:139-194"""
+        tmp_grid = -torch.ones_like(self.density_grid)
+        gs = self.cfg.grid_size
+        if self.local_step < self.cfg.update_thres:
+            bsize = self.cfg.grid_bsize or gs
+            splits = [torch.arange(gs, dtype=torch.int32, device=self.device).split(bsize) for _ in range(3)]
+            for xs in splits[0]:
+                for ys in splits[1]:
+                    for zs in splits[2]:
+                        xx, yy, zz = torch.meshgrid(xs, ys, zs, indexing='ij')
+                        coords = torch.cat([xx.reshape(-1, 1), yy.reshape(-1, 1), zz.reshape(-1, 1)], dim=-1)
+                        indices = raymarching.morton3D(coords).long()
+                        xyzs = 2 * coords.float() / (gs - 1) - 1
+                        for cas in range(self.cascade):
+                            tmp_grid[cas, indices] = self._compute_occ_sigmas(xyzs, cas)
+        else:
+            N = gs ** 3 // 4
+            for cas in range(self.cascade):
+                coords = torch.randint(0, gs, (N, 3), device=self.device)
+                indices = raymarching.morton3D(coords).long()
+                occ_indices = torch.nonzero(self.density_grid[cas] > 0).squeeze(-1)
+                rand_mask = torch.randint(0, occ_indices.shape[0], [N], dtype=torch.long, device=self.device)
+                occ_indices = occ_indices[rand_mask]
+                occ_coords = raymarching.morton3D_invert(occ_indices)
+                indices = torch.cat([indices, occ_indices], dim=0)
+                coords = torch.cat([coords, occ_coords], dim=0)
+                xyzs = 2 * coords.float() / (gs - 1) - 1
+                tmp_grid[cas, indices] = self._compute_occ_sigmas(xyzs, cas)
+
+        valid_mask = (self.density_grid >= 0) & (tmp_grid >= 0)
+        self.density_grid[valid_mask] = torch.maximum(
+            self.density_grid[valid_mask] * self.cfg.density_decay, tmp_grid[valid_mask])
+        self.mean_density = torch.mean(self.density_grid.clamp(min=0)).item()
+        density_thresh = min(self.mean_density, self.cfg.density_thresh)
+        self.density_bitfield = raymarching.packbits(self.density_grid, density_thresh, self.density_bitfield)
+        total_step = min(STEP_CTR_SIZE, self.cfg.update_iter)
+        self.mean_count = int(self.step_counter[:total_step, 0].sum().item() / total_step)
+
+    # ---- training render -----------------------------------------------------------------------
+    def sample_capacity(self, n_rays: int) -> int:
+        per_ray = self.cfg.max_steps if self.samples_per_ray_cap is None else min(self.samples_per_ray_cap,
+                                                                               self.cfg.max_steps)
+        return n_rays * per_ray
+
+    def render_train(self, rays: RayBatch, **kwargs):
+        """renderer.py:196-235 -> (image [N,3], depth [N], classes [N,nc])"""
+        if self.update_occ and (self.local_step % self.cfg.update_iter == 0):
+            self.update_state()
+        nears, fars = raymarching.near_far_from_aabb(rays.origins, rays.dirs, self.aabb, self.cfg.min_near)
+        if self.update_occ:
+            counter = self.step_counter[self.local_step % STEP_CTR_SIZE]
+            counter.zero_()
+            self.local_step += 1
+        else:
+            counter = torch.zeros(2, dtype=torch.int32, device=self.device)
+
+        self._last_counter = counter     # device-side (samples, rays) of this call; never read here
+        N = rays.origins.shape[0]
+        M = self.sample_capacity(N)
+        xyzs, _, deltas, rays_info = raymarching.march_rays_train_nosync(
+            rays.origins, rays.dirs, self.bound, self.density_bitfield, self.cascade, self.cfg.grid_size, nears, fars,
+            M, counter, 0., self.cfg.max_steps)
+        sigmas, rgbs = self.model.field(xyzs, sigma_only=False, m_dev=counter, density_scale=self.cfg.density_scale)
+        weights_sum, depth, image = _composite_train_nosync(sigmas, rgbs, deltas, rays_info, self.cfg.t_thresh)
+        classes = image[:, 3:]
+        image = image[:, :3]
+        image = image + (1 - weights_sum).unsqueeze(-1)
+        depth = torch.clamp(depth - nears, min=0) / (fars - nears)
+        return image, depth, classes
+
+    # ---- inference render ----------------------------------------------------------------------
+    @torch.no_grad()
+    def render_test(self, rays: RayBatch, **kwargs):
+        """renderer.py:237-293.  Same iteration structure (n_step = max(min(N // n_alive, 8), 1));
+        alive-ray compaction is a device scan instead of boolean-mask indexing."""
+        nears, fars = raymarching.near_far_from_aabb(rays.origins, rays.dirs, self.aabb, self.cfg.min_near)
+        N = len(rays)
+        dev = self.device
+        weights_sum = torch.zeros(N, dtype=torch.float32, device=dev)
+        depth = torch.zeros(N, dtype=torch.float32, device=dev)
+        image = torch.zeros(N, self.raymarch_channels, dtype=torch.float32, device=dev)
+        n_alive = N
+        rays_alive = torch.arange(n_alive, dtype=torch.int32, device=dev)
+        rays_alive_next = torch.empty_like(rays_alive)
+        n_out = torch.empty(1, dtype=torch.int32, device=dev)
+        rays_t = nears.clone()[:, None].contiguous()
+        step = 0
+        while step < self.cfg.max_steps:
+            if n_alive <= 0:
+                break
+            n_step = max(min(N // n_alive, 8), 1)
+            xyzs, _, deltas = raymarching.march_rays(
+                n_alive, n_step, rays_alive, rays_t, rays.origins, rays.dirs, None, self.bound, self.density_bitfield,
+                self.cascade, self.cfg.grid_size, nears, fars, 128, False, 0., self.cfg.max_steps, self.cfg.use_ndc)
+            sigmas, rgbs = self.model.field(xyzs, sigma_only=False, density_scale=self.cfg.density_scale)
+            raymarching.composite_rays(n_alive, n_step, rays_alive, rays_t, sigmas, rgbs, deltas, self.cfg.use_ndc,
+                                       weights_sum, depth, image, self.cfg.t_thresh)
+            raymarching.compact_alive(rays_alive, n_alive, rays_alive_next, n_out)
+            rays_alive, rays_alive_next = rays_alive_next, rays_alive
+            n_alive = int(n_out.item())
+            step += n_step
+        classes = image[:, 3:]
+        image = image[:, :3]
+        image = image + (1 - weights_sum).unsqueeze(-1)
+        depth = torch.clamp(depth - nears, min=0) / (fars - nears)
+        return image, depth, classes
+
+    def render(self, pose, image=None, patch: Optional[Box2D] = None, num_rays: Optional[int] = None,
+               training: bool = False, pix_subset=None) -> Dict[str, torch.Tensor]:
+        """renderer.py:295-313"""
+        output = {}
+        precrop_frac = self.precrop_frac if self._use_precrop else 1.
+        rays, output['target'] = generate_rays(pose, self.intr, image, patch=patch, precrop=precrop_frac, bsize=num_rays,
+                                               camera_flip=self.cfg.flip_camera, pix_subset=pix_subset,
+                                               device=self.device)
+        render_fn = self.render_train if training else self.render_test
+        output['rgb_map'], output['trans_map'], output['classes'] = render_fn(rays)
+        return output
+
+
+class _composite_train_nosync_fn(torch.autograd.Function):
+    """composite_rays_train over capacity-sized buffers: gradients are produced with torch.empty
+    (the backward kernel writes every sample that belongs to a ray, zeros included)."""
+
+    @staticmethod
+    def forward(ctx, sigmas, rgbs, deltas, rays, T_thresh):
+        from . import _lib as L
+        M, N, C = sigmas.shape[0], rays.shape[0], rgbs.shape[1]
+        dev = sigmas.device
+        weights_sum = torch.empty(N, dtype=torch.float32, device=dev)
+        depth = torch.empty(N, dtype=torch.float32, device=dev)
+        image = torch.empty(N, C, dtype=torch.float32, device=dev)
+        from . import profiling
+        with profiling.timed('composite_fwd'):
+            L.check(L.lib().nsr_composite_rays_train_forward(
+                L.p(sigmas), L.p(rgbs), L.p(deltas), L.p(rays), M, N, C, float(T_thresh), 0, L.p(weights_sum), L.p(depth),
+                L.p(image), L.stream()), 'composite_rays_train_forward')
+        ctx.save_for_backward(sigmas, rgbs, deltas, rays, weights_sum, image)
+        ctx.T_thresh = T_thresh
+        ctx.mark_non_differentiable(depth)
+        return weights_sum, depth, image
+
+    @staticmethod
+    def backward(ctx, grad_weights_sum, grad_depth, grad_image):
+        from . import _lib as L
+        sigmas, rgbs, deltas, rays, weights_sum, image = ctx.saved_tensors
+        M, N, C = sigmas.shape[0], rays.shape[0], rgbs.shape[1]
+        grad_weights_sum = grad_weights_sum.to(torch.float32).contiguous()
+        grad_image = grad_image.to(torch.float32).contiguous()
+        grad_sigmas = torch.empty_like(sigmas)
+        grad_rgbs = torch.empty_like(rgbs)
+        from . import profiling
+        with profiling.timed('composite_bwd'):
+            L.check(L.lib().nsr_composite_rays_train_backward(
+                L.p(grad_weights_sum), L.p(grad_image), L.p(sigmas), L.p(rgbs), L.p(deltas), L.p(rays), 0, L.p(weights_sum),
+                L.p(image), M, N, C, float(ctx.T_thresh), L.p(grad_sigmas), L.p(grad_rgbs), L.stream()),
+                'composite_rays_train_backward')
+        return grad_sigmas, grad_rgbs, None, None, None
+
+
+_composite_train_nosync = _composite_train_nosync_fn.apply

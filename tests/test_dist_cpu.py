@@ -1,0 +1,89 @@
+"""N > 1 path on CPU: world_size-2 gloo processes exercise the ray sharding and the flat
+gradient all-reduce of nerfstyle_amd.parallel (the kernels themselves need a GPU)."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import os, sys
+sys.path.insert(0, os.environ["NSR_ROOT"])
+import torch
+from nerfstyle_amd import parallel as P
+rank, local_rank, world = P.init(backend="gloo")
+assert world == 2 and P.world_size() == 2
+# ray sharding: disjoint, balanced, covering
+n = 40001
+b, e = P.shard_bounds(n, rank, world)
+sizes = [P.shard_bounds(n, r, world) for r in range(world)]
+assert sizes[0][0] == 0 and sizes[-1][1] == n and sizes[0][1] == sizes[1][0]
+assert abs((sizes[0][1] - sizes[0][0]) - (sizes[1][1] - sizes[1][0])) <= 1
+# rank-distinct pixel streams, rank-identical occupancy streams
+g = P.rank_generator(69420, rank)
+pix = torch.randperm(1000, generator=g)[:16]
+gathered = [torch.zeros_like(pix) for _ in range(world)]
+torch.distributed.all_gather(gathered, pix)
+assert not torch.equal(gathered[0], gathered[1])
+# gradient all-reduce: each rank's "gradient" of its ray shard, loss pre-divided by world
+torch.manual_seed(0)
+x = torch.randn(n, 8)
+w = torch.randn(8, requires_grad=True)
+full = ((x @ w) ** 2).mean()
+gfull, = torch.autograd.grad(full, w)
+local = ((x[b:e] @ w) ** 2).sum() / n          # global normalisation
+glocal, = torch.autograd.grad(local, w)
+flat = torch.zeros(100); flat[:8] = glocal
+P.all_reduce_sum_(flat, max_bucket_bytes=64)    # bucketed path
+assert torch.allclose(flat[:8], gfull, atol=1e-5), (flat[:8], gfull)
+flat2 = torch.full((10,), float(rank + 1)); P.all_reduce_sum_(flat2)
+assert torch.equal(flat2, torch.full((10,), 3.0))
+t = torch.arange(5.) * (rank + 1); P.broadcast_(t, 0)
+assert torch.equal(t, torch.arange(5.))
+assert P.max_over_ranks(float(rank), "cpu") == 1.0
+P.barrier()
+print("RANK_OK", rank)
+'''
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_world_size_2_gloo(tmp_path):
+    script = tmp_path / 'worker.py'
+    script.write_text(WORKER)
+    port = _free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE='2', MASTER_ADDR='127.0.0.1',
+                   MASTER_PORT=str(port), NSR_ROOT=ROOT, OMP_NUM_THREADS='2')
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                                      text=True))
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=240)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            out, _ = p.communicate()
+        outs.append(out)
+    for rank, (p, out) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, out
+        assert 'RANK_OK {}'.format(rank) in out
+
+
+def test_single_process_is_noop():
+    import torch
+    from nerfstyle_amd import parallel as P
+    t = torch.ones(4)
+    assert P.all_reduce_sum_(t) is t and P.world_size() == 1
+    assert P.shard_bounds(10, 0, 1) == (0, 10)
+    assert P.shard_bounds(10, 2, 3) == (7, 10) and P.shard_bounds(10, 0, 3) == (0, 4)

@@ -1,0 +1,238 @@
+"""GPU parity of the encode / MLP / fused-field kernels against the CPU oracle.
+
+Tolerances (floating point, stated per test):
+  * hash-grid encode, fp32 tables: fp32 interpolation with FMA vs the oracle's non-contracted
+    fp32 -> max abs error <= 4e-6 * max|table|; corner ROWS are checked bit-exactly through a table
+    whose entries encode their own row index.
+  * fp16 tables: inputs identical halves; kernel accumulates in fp32 and rounds once, the reference
+    (and the oracle in half_accum mode) rounds after every corner -> <= 2 half ulps of the result.
+  * MLP / fused field (f16 or bf16 MFMA, fp32 accumulate): compared with the oracle emulating the
+    same roundings (rel L2 <= 2e-3 f16 / 1e-2 bf16) and with the pure fp32 restatement
+    (rel L2 <= 5e-3 f16 / 3e-2 bf16).  tinycudann itself is absent: "parity unpinned" there.
+  * backward: fp32 autograd of the PyTorch restatement; rel L2 <= 2e-2 (f16) / 5e-2 (bf16) per
+    parameter block, atomics make the summation order run-dependent.
+"""
+import numpy as np
+import pytest
+import torch
+
+from helpers import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+def T(a, dev):
+    return torch.as_tensor(np.ascontiguousarray(a), device=dev)
+
+
+# ---------------------------------------------------------------------------------------------
+# stand-alone GridEncoder
+# ---------------------------------------------------------------------------------------------
+def _enc(O, align=True):
+    from nerfstyle_amd.gridencoder import GridEncoder
+    pls = O.per_level_scale_from_cfg()
+    return GridEncoder(3, 16, 2, pls, 16, 19, gridtype='hash', align_corners=align), pls
+
+
+@pytest.mark.parametrize('align', [True, False])
+def test_grid_encode_forward_fp32_and_rows(O, dev, align):
+    enc, pls = _enc(O, align)
+    rng = np.random.default_rng(5)
+    R = enc.embeddings.shape[0]
+    emb = (rng.random((R, 2)) * 2 - 1).astype(np.float32)
+    B = 20011
+    x = rng.random((B, 3)).astype(np.float32)
+    x[:5] = [[1.2, 0.5, 0.5], [0.5, -0.1, 0.5], [0, 0, 0], [1, 1, 1], [0.5, 0.5, 1.0]]
+    off = enc.offsets.numpy()
+    enc = enc.to(dev)
+    with torch.no_grad():
+        enc.embeddings.copy_(T(emb, dev))
+        out = enc(T(x, dev) * 2 - 1).cpu().numpy()              # GridEncoder.forward maps [-1,1] -> [0,1]
+    xin = ((x * 2 - 1) + np.float32(1)) / np.float32(2)
+    ref = O.grid_encode_forward(xin.astype(np.float32), emb, off, pls, 16, 0, align, 0)
+    assert np.abs(out - ref).max() <= 4e-6
+    assert np.all(out[:2] == 0)                                 # OOB rows
+    # bit-exact corner rows: table entry = (row index, 0); out feature 0 = sum_w * row. Use one-hot probes instead:
+    rows = O.grid_corner_rows(xin.astype(np.float32), off, pls, 16, 0, align, 0)      # [L, B, 8]
+    probe = np.zeros((R, 2), np.float32)
+    lvl = 9
+    sel = np.unique(rows[lvl, 5:200].reshape(-1).astype(np.int64))
+    probe[off[lvl] + sel, 0] = 1.0                             # all corners of those samples -> weights sum to 1
+    with torch.no_grad():
+        enc.embeddings.copy_(T(probe, dev))
+        o2 = enc(T(x, dev) * 2 - 1).cpu().numpy().reshape(B, 16, 2)
+    assert np.abs(o2[5:200, lvl, 0] - 1.0).max() < 1e-6         # every corner row the kernel touched is in the oracle's set
+    assert np.all(o2[5:200, :lvl, 0] == 0)
+
+
+def test_grid_encode_half_tables_and_backward(O, dev):
+    enc, pls = _enc(O, True)
+    rng = np.random.default_rng(6)
+    R = enc.embeddings.shape[0]
+    emb = O.round_f16((rng.random((R, 2)) * 2 - 1).astype(np.float32))
+    B = 8191
+    x = (0.5 + 0.5 * rng.random((B, 3))).astype(np.float32)
+    off = enc.offsets.numpy()
+    enc = enc.to(dev)
+    with torch.no_grad():
+        enc.embeddings.copy_(T(emb, dev))
+    xt = T(x * 2 - 1, dev)
+    with torch.autocast('cuda', dtype=torch.float16):
+        out = enc(xt)
+    assert out.dtype == torch.float16
+    ref = O.grid_encode_forward(x, emb, off, pls, 16, 0, True, 0, half_accum=True)
+    ref32 = O.grid_encode_forward(x, emb, off, pls, 16, 0, True, 0, half_accum=False)
+    o = out.float().cpu().numpy()
+    assert np.abs(o - O.round_f16(ref32)).max() == 0 or np.abs(o - ref32).max() <= 1e-3   # one rounding of the fp32 sum
+    assert np.abs(o - ref).max() <= 2 * 2.0 ** -10                                          # vs per-corner rounding
+    # backward, fp32 path
+    out = enc(xt)
+    g = rng.standard_normal(out.shape).astype(np.float32)
+    out.backward(T(g, dev))
+    ge = enc.embeddings.grad.cpu().numpy()
+    ge_ref = O.grid_encode_backward(g, x, off, R, 2, pls, 16, 0, True, 0)
+    assert rel_l2(ge, ge_ref) < 1e-5
+    assert np.array_equal(ge == 0, ge_ref == 0)
+
+
+# ---------------------------------------------------------------------------------------------
+# stand-alone Network (tcnn.Network replacement)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('cfg', [(32, 1, 1, 'None'), (32, 16, 1, 'None'), (32, 5, 1, 'None'), (16, 3, 2, 'Sigmoid')])
+@pytest.mark.parametrize('dt', ['f16', 'bf16'])
+def test_network_forward_backward(O, dev, cfg, dt):
+    from nerfstyle_amd.network import Network
+    from oracle import torch_port as TP
+    n_in, n_out, nh, act = cfg
+    tdt = torch.float16 if dt == 'f16' else torch.bfloat16
+    net = Network(n_in, n_out, {'otype': 'FullyFusedMLP', 'activation': 'ReLU', 'output_activation': act, 'n_neurons': 64,
+                                'n_hidden_layers': nh}, seed=7, dtype=tdt).to(dev)
+    rng = np.random.default_rng(8)
+    M = 10007                                                   # ragged: not a multiple of 16
+    x = rng.standard_normal((M, n_in)).astype(np.float32)
+    p = net.params.detach().cpu().numpy()
+    xt = T(x, dev).requires_grad_()
+    y = net(xt)
+    assert y.shape == (M, n_out)
+    oa = 'sigmoid' if act == 'Sigmoid' else 'none'
+    ref_emul = O.mlp_forward(x, p, n_in, n_out, 64, nh, oa, half=dt)
+    ref_f32 = O.mlp_forward(x, p, n_in, n_out, 64, nh, oa, half=None)
+    yn = y.detach().cpu().numpy()
+    assert rel_l2(yn, ref_emul) < (2e-3 if dt == 'f16' else 1e-2)
+    assert rel_l2(yn, ref_f32) < (5e-3 if dt == 'f16' else 3e-2)
+    # backward vs fp32 autograd
+    g = rng.standard_normal(yn.shape).astype(np.float32)
+    y.backward(T(g, dev))
+    xc = torch.tensor(x, requires_grad=True)
+    pc = torch.tensor(p, requires_grad=True)
+    TP.mlp(xc, pc, n_in, n_out, nh, 64, oa).backward(torch.tensor(g))
+    tol = 2e-2 if dt == 'f16' else 5e-2
+    assert rel_l2(xt.grad.cpu().numpy(), xc.grad.numpy()) < tol
+    gp, gp_ref = net.params.grad.cpu().numpy(), pc.grad.numpy()
+    assert rel_l2(gp, gp_ref) < tol
+    # padded output rows receive no gradient
+    assert np.all(gp.reshape(-1)[-(16 - n_out) * 64:] == 0) if n_out < 16 else True
+
+
+# ---------------------------------------------------------------------------------------------
+# fused field
+# ---------------------------------------------------------------------------------------------
+def _field_pair(dev, dt, table_dtype, nc=5, table_scale=0.5):
+    from nerfstyle_amd.common import BBox
+    from nerfstyle_amd.config import NetworkConfig
+    from nerfstyle_amd.style_nerf import StyleTCNerf
+    from oracle import torch_port as TP
+    ref = TP.Field(num_classes=nc, table_scale=table_scale)
+    tdt = torch.float16 if dt == 'f16' else torch.bfloat16
+    m = StyleTCNerf(NetworkConfig(), BBox.from_radius(2.0), nc, enc_dtype=table_dtype, use_dir=False, compute_dtype=tdt)
+    sd = m.state_dict()
+    sd['x_density_embedder.embeddings'] = ref.emb_density.detach()
+    sd['x_color_embedder.embeddings'] = ref.emb_color.detach()
+    sd['density_net.params'] = ref.p_density.detach()
+    sd['color1_net.params'] = ref.p_color1.detach()
+    sd['color2_net.params'] = ref.p_color2.detach()
+    sd['class_net.params'] = ref.p_class.detach()
+    m.load_state_dict(sd)
+    return m.to(dev), ref
+
+
+def _oracle_params(O, ref, table_half=False):
+    return O.FieldParams(ref.emb_density.detach().numpy(), ref.emb_color.detach().numpy(), ref.p_density.detach().numpy(),
+                         ref.p_color1.detach().numpy(), ref.p_color2.detach().numpy(), ref.p_class.detach().numpy(),
+                         ref.offsets, ref.pls, num_classes=ref.nc)
+
+
+@pytest.mark.parametrize('dt,table_dtype', [('f16', torch.float32), ('f16', None), ('bf16', torch.float32)])
+def test_field_forward(O, dev, dt, table_dtype):
+    m, ref = _field_pair(dev, dt, table_dtype)
+    rng = np.random.default_rng(10)
+    M = 12345
+    pts = (rng.random((M, 3)) * 4 - 2).astype(np.float32)
+    pts[:3] = [[2, 2, 2], [-2, -2, -2], [0, 0, 0]]
+    rgbs, sig = m(T(pts, dev), dirs=T(pts, dev))
+    assert rgbs.shape == (M, 8) and sig.shape == (M, 1)
+    fp = _oracle_params(O, ref)
+    half = table_dtype is None
+    out_e, sig_e, logit_e = O.field_forward(fp, pts, half=dt, table_half=half)
+    out_f, sig_f, _ = O.field_forward(fp, pts, half=None, table_half=half)
+    rn, sn = rgbs.detach().cpu().numpy(), sig.detach().cpu().numpy()[:, 0]
+    tol_e, tol_f = (2e-3, 5e-3) if dt == 'f16' else (1e-2, 3e-2)
+    assert rel_l2(rn, out_e) < tol_e and rel_l2(rn, out_f) < tol_f
+    # sigma = exp(logit): compare in log space (logit abs error), it spans orders of magnitude
+    assert np.abs(np.log(sn) - logit_e).max() < (2e-2 if dt == 'f16' else 1e-1)
+    # sigma-only branch (style_nerf.py:125-126) gives the same sigma
+    s_only = m(T(pts, dev))
+    assert torch.equal(s_only, sig)
+    # device-side sample count: outputs past the count are untouched
+    cnt = torch.tensor([1000, 0], dtype=torch.int32, device=dev)
+    s2, r2 = m.field(T(pts, dev), False, cnt)
+    assert torch.equal(s2[:1000], sig[:1000, 0]) and torch.equal(r2[:1000], rgbs[:1000])
+
+
+def test_field_forward_psnr_vs_fp32_restatement(O, dev):
+    """The metric's PSNR definition (utils/__init__.py:323-325) applied to per-sample colours:
+    f16 MFMA vs the fp32 restatement must clear the 40 dB bar with margin."""
+    m, ref = _field_pair(dev, 'f16', torch.float32)
+    rng = np.random.default_rng(12)
+    pts = (rng.random((50000, 3)) * 4 - 2).astype(np.float32)
+    rgbs, _ = m(T(pts, dev), dirs=T(pts, dev))
+    out_f, _, _ = O.field_forward(_oracle_params(O, ref), pts)
+    mse = float(np.mean((rgbs.cpu().numpy()[:, :3] - out_f[:, :3]) ** 2))
+    assert O.compute_psnr(mse) > 55.0
+
+
+@pytest.mark.parametrize('dt,table_dtype', [('f16', torch.float32), ('bf16', torch.float32), ('f16', None)])
+def test_field_backward(O, dev, dt, table_dtype):
+    m, ref = _field_pair(dev, dt, table_dtype)
+    rng = np.random.default_rng(14)
+    M = 4099
+    pts = (rng.random((M, 3)) * 4 - 2).astype(np.float32)
+    gs = (rng.standard_normal(M) * 1e-2).astype(np.float32)
+    gr = rng.standard_normal((M, 8)).astype(np.float32)
+    sig, rgbs = m.field(T(pts, dev), False)
+    ((sig * T(gs, dev)).sum() + (rgbs * T(gr, dev)).sum()).backward()
+    out_r, sig_r = ref(torch.tensor(pts))
+    ((sig_r[:, 0] * torch.tensor(gs)).sum() + (out_r * torch.tensor(gr)).sum()).backward()
+    ga = m.arena.grad.cpu().numpy()
+    gt = ga[:m.table_elems].reshape(m.rows, 2, 2)
+    tol = 2e-2 if dt == 'f16' else 5e-2
+    assert rel_l2(gt[:, 0, :], ref.emb_density.grad.numpy()) < tol
+    assert rel_l2(gt[:, 1, :], ref.emb_color.grad.numpy()) < tol
+    gm = ga[m.table_elems:]
+    for name, off, n, p in (('density', 0, 3072, ref.p_density), ('color1', 3072, 3072, ref.p_color1),
+                            ('color2', 6144, 6144, ref.p_color2), ('class', 12288, 3072, ref.p_class)):
+        assert rel_l2(gm[off:off + n], p.grad.numpy()) < tol, name
+    # rows nobody touched stay exactly zero (scatter goes only where the gather went)
+    assert not np.any((gt[:, 0, :] != 0) & (ref.emb_density.grad.numpy() == 0))
+    assert not np.any((gt[:, 1, :] != 0) & (ref.emb_color.grad.numpy() == 0))
+    # accumulation semantics: a second backward doubles the gradient
+    sig, rgbs = m.field(T(pts, dev), False)
+    ((sig * T(gs, dev)).sum() + (rgbs * T(gr, dev)).sum()).backward()
+    assert rel_l2(m.arena.grad.cpu().numpy(), 2 * ga) < 1e-3
+    # stylisation mode: only the colour table is trained (trainers/style.py:25)
+    m.arena.grad.zero_()
+    m.train_density_table = False
+    sig, rgbs = m.field(T(pts, dev), False)
+    ((sig * T(gs, dev)).sum() + (rgbs * T(gr, dev)).sum()).backward()
+    gt2 = m.arena.grad.cpu().numpy()[:m.table_elems].reshape(m.rows, 2, 2)
+    assert np.all(gt2[:, 0, :] == 0) and rel_l2(gt2[:, 1, :], gt[:, 1, :]) < 1e-3
