@@ -27,8 +27,10 @@ k_field_fwd(FieldArgs a) {
     const int s = lane & 15, g = lane >> 4;
     const TT *tables = reinterpret_cast<const TT *>(a.tables);
     const uint32_t lb = field_logical_block();
-    const uint32_t t_begin = lb * a.tiles_per_block;
-    const uint32_t t_end = min(t_begin + a.tiles_per_block, ntiles);
+    // split by the DEVICE-side sample count (M is only a capacity): every block gets work
+    const uint32_t tpb = (ntiles + gridDim.x - 1) / gridDim.x;
+    const uint32_t t_begin = lb * tpb;
+    const uint32_t t_end = min(t_begin + tpb, ntiles);
 
     for (uint32_t tile = t_begin + wave; tile < t_end; tile += 4) {
         const uint32_t m = tile * 16 + s;

@@ -28,7 +28,9 @@ constexpr int BW_D1T = 13312;    // d1^T  [32 x 64]  4 frag32
 constexpr int BW_TOTAL = 15360;
 
 constexpr int BWD_THREADS = 512;
-constexpr size_t BWD_LDS_BYTES = (size_t)FW_TOTAL * 2 + (size_t)BW_TOTAL * 2 + (size_t)P_TOTAL * 4 + 16 * sizeof(NsrLevel);
+constexpr size_t BWD_QUEUE_BYTES_PER_WAVE = 192 * 16 + 192 * 4;
+constexpr size_t BWD_LDS_BYTES = (size_t)FW_TOTAL * 2 + (size_t)BW_TOTAL * 2 + (size_t)P_TOTAL * 4 + 16 * sizeof(NsrLevel) +
+                                 (BWD_THREADS / 64) * BWD_QUEUE_BYTES_PER_WAVE;
 
 struct FieldBwdArgs {
     FieldArgs f;
@@ -99,14 +101,73 @@ __device__ __forceinline__ void field_mask_pack(const f4v (&gacc)[4], const s8v 
                     mm_round4<CD, false>(mm_relu_mask(gacc[3], mm_hi(act[1]))));
 }
 
-// Scatter one level's gradient (both encoders) into the interleaved fp32 gradient table.
-__device__ __forceinline__ void field_scatter_level(const NsrLevel &lv, float *__restrict__ gt, float u0, float u1, float u2,
-                                                    float gd0, float gd1, float gc0, float gc1, bool td, bool tc) {
-    float f[3];
-    uint32_t c[3];
-    nsr_grid_locate(u0, lv.resolution, 1, f[0], c[0]);
-    nsr_grid_locate(u1, lv.resolution, 1, f[1], c[1]);
-    nsr_grid_locate(u2, lv.resolution, 1, f[2], c[2]);
+// ---- table scatter ----------------------------------------------------------------------------
+// Global float atomics are priced per 64-byte request at the memory side (~1e10 requests/s chip
+// wide), not per byte: 64 lanes adding one dword each to 64 different rows cost 64 requests.  The
+// naive scatter (4 dword atomics per corner per lane) is 512 requests per sample and ran the whole
+// backward at 21 M samples/s.  Two reductions of the request count, both exact up to fp32
+// summation order:
+//   1. the 16 lanes of a DPP row hold 16 CONSECUTIVE samples of one level; consecutive samples of
+//      a ray share cells on the coarse and middle levels, so equal rows form runs: a segmented
+//      scan over the row (v_mov_dpp row_shr) sums each run and only its last lane emits a record;
+//   2. records {row, d0, d1, c0, c1} go through a small per-wave LDS queue and are drained 16 per
+//      wave-instruction with 4 lanes per record, so the four dwords of an interleaved row leave as
+//      ONE 16-byte request instead of four 4-byte ones.
+constexpr int SCQ_CAP = 192;     // records per wave; drained when >= SCQ_CAP - 64
+struct ScatterQueue {
+    uint32_t *rows;              // [SCQ_CAP]
+    float4 *vals;                // [SCQ_CAP]
+    int count;                   // wave-uniform
+};
+
+template <int K>
+__device__ __forceinline__ float dpp_shr_f(float v, float fill) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, fill), __builtin_bit_cast(int, v),
+                                                                 0x110 + K, 0xF, 0xF, false));
+}
+template <int K>
+__device__ __forceinline__ uint32_t dpp_shr_u(uint32_t v, uint32_t fill) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)fill, (int)v, 0x110 + K, 0xF, 0xF, false);
+}
+__device__ __forceinline__ uint32_t dpp_shl1_u(uint32_t v, uint32_t fill) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)fill, (int)v, 0x101, 0xF, 0xF, false);
+}
+
+template <int K>
+__device__ __forceinline__ void seg_step(float4 &v, uint32_t &f) {
+    const float a = dpp_shr_f<K>(v.x, 0.f), b = dpp_shr_f<K>(v.y, 0.f), c = dpp_shr_f<K>(v.z, 0.f), d = dpp_shr_f<K>(v.w, 0.f);
+    const uint32_t fu = dpp_shr_u<K>(f, 1u);      // lanes shifted in from outside the row count as heads
+    if (!f) { v.x += a; v.y += b; v.z += c; v.w += d; }
+    f |= fu;
+}
+
+__device__ __forceinline__ void scq_drain(ScatterQueue &q, float *__restrict__ gt, int lane, bool td, bool tc) {
+    __builtin_amdgcn_wave_barrier();
+    const int t = lane >> 2, i = lane & 3;
+    const bool on = (i < 2) ? td : tc;
+    for (int base = 0; base < q.count; base += 16) {
+        const int rec = base + t;
+        if (rec < q.count && on) {
+            const uint32_t row = q.rows[rec];
+            const float v = reinterpret_cast<const float *>(q.vals)[rec * 4 + i];
+            atomicAdd(gt + (size_t)row * 4 + i, v);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    q.count = 0;
+}
+
+// One level, all 8 corners, for the 16-sample tile (this lane = one sample of one level group).
+__device__ __forceinline__ void field_scatter_level(const NsrLevel &lv, ScatterQueue &q, float *__restrict__ gt, float u0, float u1,
+                                                    float u2, bool live, float gd0, float gd1, float gc0, float gc1, int lane,
+                                                    bool td, bool tc) {
+    float f[3] = {0.f, 0.f, 0.f};
+    uint32_t c[3] = {0u, 0u, 0u};
+    if (live) {
+        nsr_grid_locate(u0, lv.resolution, 1, f[0], c[0]);
+        nsr_grid_locate(u1, lv.resolution, 1, f[1], c[1]);
+        nsr_grid_locate(u2, lv.resolution, 1, f[2], c[2]);
+    }
 #pragma unroll
     for (uint32_t idx = 0; idx < 8; idx++) {
         float w = 1;
@@ -116,9 +177,24 @@ __device__ __forceinline__ void field_scatter_level(const NsrLevel &lv, float *_
             if ((idx & (1u << d)) == 0) { w *= 1 - f[d]; p[d] = c[d]; }
             else { w *= f[d]; p[d] = c[d] + 1; }
         }
-        float *row = gt + (size_t)(lv.offset + nsr_grid_row(lv, p[0], p[1], p[2], 0u)) * 4;
-        if (td) { atomicAdd(row + 0, w * gd0); atomicAdd(row + 1, w * gd1); }
-        if (tc) { atomicAdd(row + 2, w * gc0); atomicAdd(row + 3, w * gc1); }
+        // dead lanes get unique keys so they never merge with anything and never emit
+        const uint32_t key = live ? lv.offset + nsr_grid_row(lv, p[0], p[1], p[2], 0u) : (0xFFFFFF00u | (uint32_t)lane);
+        float4 v = live ? make_float4(w * gd0, w * gd1, w * gc0, w * gc1) : make_float4(0.f, 0.f, 0.f, 0.f);
+        uint32_t head = (dpp_shr_u<1>(key, 0xFFFFFFFFu) != key) ? 1u : 0u;
+        const bool tail = dpp_shl1_u(key, 0xFFFFFFFFu) != key;
+        seg_step<1>(v, head);
+        seg_step<2>(v, head);
+        seg_step<4>(v, head);
+        seg_step<8>(v, head);
+        const bool push = tail && live;
+        const unsigned long long mask = __ballot(push);
+        if (push) {
+            const int slot = q.count + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+            q.rows[slot] = key;
+            q.vals[slot] = v;
+        }
+        q.count += (int)__popcll(mask);
+        if (q.count >= SCQ_CAP - 64) scq_drain(q, gt, lane, td, tc);
     }
 }
 
@@ -143,10 +219,21 @@ k_field_bwd(FieldBwdArgs b) {
     const int s = lane & 15, g = lane >> 4;
     const TT *tables = reinterpret_cast<const TT *>(a.tables);
     const uint32_t lb = field_logical_block();
-    const uint32_t t_begin = lb * a.tiles_per_block;
-    const uint32_t t_end = min(t_begin + a.tiles_per_block, ntiles);
+    // split by the DEVICE-side sample count (M is only a capacity): every block gets work
+    const uint32_t tpb = (ntiles + gridDim.x - 1) / gridDim.x;
+    const uint32_t t_begin = lb * tpb;
+    const uint32_t t_end = min(t_begin + tpb, ntiles);
     const s4v ident = mm_identity_frag<CD>(lane);
     const int nc = (int)b.nc;
+    ScatterQueue q;
+    {
+        char *qbase = smem + (size_t)(FW_TOTAL + BW_TOTAL) * 2 + (size_t)P_TOTAL * 4 + 16 * sizeof(NsrLevel) +
+                      (size_t)wave * BWD_QUEUE_BYTES_PER_WAVE;
+        q.vals = reinterpret_cast<float4 *>(qbase);
+        q.rows = reinterpret_cast<uint32_t *>(qbase + SCQ_CAP * 16);
+        q.count = 0;
+    }
+    const bool td = b.train_density != 0, tc = b.train_color != 0;
 
     for (uint32_t tile = t_begin + wave; tile < t_end; tile += BWD_THREADS / 64) {
         const uint32_t m = tile * 16 + s;
@@ -281,17 +368,18 @@ k_field_bwd(FieldBwdArgs b) {
         // ================= table scatter =======================================================
         // gxd[t][2*(i&1)+f] is d L / d feature f of level lvl[i] (t = i >> 1): same lane<->level map
         // as the forward encode.
-        if (live && (b.train_density || b.train_color)) {
+        if (td || tc) {
             const int lvl[4] = {2 * g, 2 * g + 1, 8 + 2 * g, 9 + 2 * g};
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 const NsrLevel lv = lds_lv[lvl[i]];
                 const int t = i >> 1, e0 = 2 * (i & 1);
-                field_scatter_level(lv, b.grad_tables, u0, u1, u2, gxd[t][e0], gxd[t][e0 + 1], gxc[t][e0], gxc[t][e0 + 1],
-                                    b.train_density != 0, b.train_color != 0);
+                field_scatter_level(lv, q, b.grad_tables, u0, u1, u2, live, gxd[t][e0], gxd[t][e0 + 1], gxc[t][e0], gxc[t][e0 + 1],
+                                    lane, td, tc);
             }
         }
     }
+    if (td || tc) scq_drain(q, b.grad_tables, lane, td, tc);
 
     // ---- flush the workgroup's weight gradients ---------------------------------------------------
     __syncthreads();

@@ -40,13 +40,13 @@ def level_resolution(level, S, H):
 
 
 def _row_index(pg, res, size, gridtype=0, style=0):
-    """gridencoder.cu:55-80 for int64 tensors pg [B,3] (uint32 wrap-around emulated with & mask)."""
+    """gridencoder.cu:55-80 for int64 tensors pg [..., 3] (uint32 wrap-around emulated with & mask)."""
     M32 = 0xFFFFFFFF
-    stride, index = 1, torch.zeros(pg.shape[0], dtype=torch.int64)
+    stride, index = 1, torch.zeros(pg.shape[:-1], dtype=torch.int64)
     for d in range(3):
         if stride > size:
             break
-        index = (index + pg[:, d] * stride) & M32
+        index = (index + pg[..., d] * stride) & M32
         stride = (stride * (res + 1)) & M32
     if stride <= size:
         index = (index + style * stride) & M32
@@ -54,17 +54,23 @@ def _row_index(pg, res, size, gridtype=0, style=0):
     if gridtype == 0 and stride > size:
         index = torch.zeros_like(index)
         for d in range(3):
-            index = index ^ ((pg[:, d] * PRIMES[d]) & M32)
+            index = index ^ ((pg[..., d] * PRIMES[d]) & M32)
         index = index ^ ((style * 3674653429) & M32)
     return index % size
 
 
-def grid_encode(x, emb, offsets, per_level_scale, base_resolution=16, align_corners=True, gridtype=0):
-    """x [B,3] float32 in [0,1]; emb [rows, C] (requires_grad ok) -> [B, L*C]."""
+_CORNERS = torch.tensor([[(idx >> d) & 1 for d in range(3)] for idx in range(8)], dtype=torch.int64)   # [8,3]
+
+
+def grid_encode(x, emb, offsets, per_level_scale, base_resolution=16, align_corners=True, gridtype=0, sparse_grad=False):
+    """x [B,3] float32 in [0,1]; emb [rows, C] (requires_grad ok) -> [B, L*C].  One gather of
+    [B,8] rows per level (the 8 corners are vectorised; weights multiply in d = 0,1,2 order).
+    sparse_grad: table gradients as sparse tensors (no dense [rows, C] zero-fill per level)."""
     S = np.float32(np.log2(per_level_scale))
     L = len(offsets) - 1
     outs = []
     oob = ((x < 0) | (x > 1)).any(dim=1)
+    cf = _CORNERS.to(x.dtype)
     for l in range(L):
         res = level_resolution(l, S, base_resolution)
         size = int(offsets[l + 1] - offsets[l])
@@ -72,35 +78,36 @@ def grid_encode(x, emb, offsets, per_level_scale, base_resolution=16, align_corn
         pos = x * scale + (0.0 if align_corners else 0.5)
         pg = torch.minimum(torch.floor(pos), torch.tensor(float(res - 1)))
         frac = pos - pg
-        pg = pg.to(torch.int64)
-        acc = 0
-        for idx in range(8):
-            w = torch.ones(x.shape[0], dtype=x.dtype)
-            pgl = pg.clone()
-            for d in range(3):
-                if (idx >> d) & 1:
-                    w = w * frac[:, d]
-                    pgl[:, d] += 1
-                else:
-                    w = w * (1 - frac[:, d])
-            rows = _row_index(pgl, res, size, gridtype) + int(offsets[l])
-            acc = acc + w[:, None] * emb[rows]
+        pgl = pg.to(torch.int64)[:, None, :] + _CORNERS[None]                       # [B,8,3]
+        wd = frac[:, None, :] * cf[None] + (1 - frac[:, None, :]) * (1 - cf[None])   # [B,8,3]
+        w = wd[..., 0] * wd[..., 1] * wd[..., 2]
+        rows = _row_index(pgl, res, size, gridtype) + int(offsets[l])                # [B,8]
+        acc = (w[..., None] * torch.nn.functional.embedding(rows, emb, sparse=sparse_grad)).sum(dim=1)
         acc = torch.where(oob[:, None], torch.zeros_like(acc), acc)
         outs.append(acc)
     return torch.cat(outs, dim=1)
 
 
-def mlp(x, params, n_in, n_out, n_hidden_layers=1, n_neurons=64, out_act='none'):
+def quant(x, half):
+    """Round to f16 / bf16 with a straight-through gradient: emulates the kernels' operand rounding
+    so that ReLU masks (and therefore gradients) are comparable bit pattern for bit pattern."""
+    if half is None:
+        return x
+    dt = torch.float16 if half == 'f16' else torch.bfloat16
+    return x + (x.detach().to(dt).to(x.dtype) - x.detach())
+
+
+def mlp(x, params, n_in, n_out, n_hidden_layers=1, n_neurons=64, out_act='none', half=None):
     pad16 = lambda v: (v + 15) // 16 * 16
     d, p = pad16(n_in), 0
     shapes = [(n_neurons, d)] + [(n_neurons, n_neurons)] * (n_hidden_layers - 1) + [(pad16(n_out), n_neurons)]
-    a = x
+    a = quant(x, half)
     for li, (o, i) in enumerate(shapes):
-        w = params[p:p + o * i].view(o, i)
+        w = quant(params[p:p + o * i].view(o, i), half)
         p += o * i
         a = a @ w.t()
         if li < len(shapes) - 1:
-            a = torch.relu(a)
+            a = quant(torch.relu(a), half)
     a = a[:, :n_out]
     return torch.sigmoid(a) if out_act == 'sigmoid' else a
 
@@ -120,9 +127,9 @@ class TruncExp(torch.autograd.Function):
 class Field(torch.nn.Module):
     """style_nerf.py:12-142 with use_dir=False, fp32."""
 
-    def __init__(self, num_classes=5, bound=2.0, seed=80000, table_scale=1e-4):
+    def __init__(self, num_classes=5, bound=2.0, seed=80000, table_scale=1e-4, sparse_grad=False):
         super().__init__()
-        self.bound, self.nc = bound, num_classes
+        self.bound, self.nc, self.sparse_grad = bound, num_classes, sparse_grad
         self.pls = float(np.exp2(np.log2(1024 * (2 * bound) / 16) / 15))   # tcnn_nerf.py:20-22, bbox size 2*bound
         self.offsets = grid_offsets(16, self.pls, 16, 19, True)
         g = torch.Generator().manual_seed(seed)
@@ -142,17 +149,21 @@ class Field(torch.nn.Module):
         x = (pts + self.bound) / (2 * self.bound)      # BBox.normalize, common.py:276-288
         return (x + 1) / 2                             # grid.py:177 with bound = 1
 
-    def forward(self, pts, sigma_only=False):
+    def forward(self, pts, sigma_only=False, half=None, table_half=False):
+        """half in {None,'f16','bf16'}: emulate the kernels' operand rounding (straight-through);
+        table_half: gather from f16-rounded tables (the AMP copy)."""
         x = self.encoder_input(pts)
-        xd = grid_encode(x, self.emb_density, self.offsets, self.pls)
-        logit = mlp(xd, self.p_density, 32, 1)
+        ed = quant(self.emb_density, 'f16') if table_half else self.emb_density
+        xd = grid_encode(x, ed, self.offsets, self.pls, sparse_grad=self.sparse_grad)
+        logit = mlp(xd, self.p_density, 32, 1, half=half)
         sigmas = TruncExp.apply(logit)
         if sigma_only:
             return sigmas
-        xc = grid_encode(x, self.emb_color, self.offsets, self.pls)
-        classes = mlp(xc, self.p_class, 32, self.nc)
-        c1 = mlp(xc, self.p_color1, 32, 16)
-        rgb = mlp(c1, self.p_color2, 16, 3, n_hidden_layers=2, out_act='sigmoid')
+        ec = quant(self.emb_color, 'f16') if table_half else self.emb_color
+        xc = grid_encode(x, ec, self.offsets, self.pls, sparse_grad=self.sparse_grad)
+        classes = mlp(xc, self.p_class, 32, self.nc, half=half)
+        c1 = mlp(xc, self.p_color1, 32, 16, half=half)
+        rgb = mlp(c1, self.p_color2, 16, 3, n_hidden_layers=2, out_act='sigmoid', half=half)
         return torch.cat((rgb, classes), dim=1), sigmas
 
 

@@ -82,7 +82,7 @@ def test_grid_encode_half_tables_and_backward(O, dev):
     assert out.dtype == torch.float16
     ref = O.grid_encode_forward(x, emb, off, pls, 16, 0, True, 0, half_accum=True)
     ref32 = O.grid_encode_forward(x, emb, off, pls, 16, 0, True, 0, half_accum=False)
-    o = out.float().cpu().numpy()
+    o = out.detach().float().cpu().numpy()
     assert np.abs(o - O.round_f16(ref32)).max() == 0 or np.abs(o - ref32).max() <= 1e-3   # one rounding of the fp32 sum
     assert np.abs(o - ref).max() <= 2 * 2.0 ** -10                                          # vs per-corner rounding
     # backward, fp32 path
@@ -120,16 +120,18 @@ def test_network_forward_backward(O, dev, cfg, dt):
     yn = y.detach().cpu().numpy()
     assert rel_l2(yn, ref_emul) < (2e-3 if dt == 'f16' else 1e-2)
     assert rel_l2(yn, ref_f32) < (5e-3 if dt == 'f16' else 3e-2)
-    # backward vs fp32 autograd
+    # backward: (a) autograd through a forward that emulates the operand rounding (same ReLU masks):
+    # tight; (b) pure fp32 autograd: loose -- rounded pre-activations flip a few ReLU masks per
+    # thousand samples, each flip moves that sample's gradient by O(1/sqrt(width))
     g = rng.standard_normal(yn.shape).astype(np.float32)
     y.backward(T(g, dev))
-    xc = torch.tensor(x, requires_grad=True)
-    pc = torch.tensor(p, requires_grad=True)
-    TP.mlp(xc, pc, n_in, n_out, nh, 64, oa).backward(torch.tensor(g))
-    tol = 2e-2 if dt == 'f16' else 5e-2
-    assert rel_l2(xt.grad.cpu().numpy(), xc.grad.numpy()) < tol
-    gp, gp_ref = net.params.grad.cpu().numpy(), pc.grad.numpy()
-    assert rel_l2(gp, gp_ref) < tol
+    gp = net.params.grad.cpu().numpy()
+    for half, tol in ((dt, 4e-3 if dt == 'f16' else 2.5e-2), (None, 5e-2 if dt == 'f16' else 1.5e-1)):
+        xc = torch.tensor(x, requires_grad=True)
+        pc = torch.tensor(p, requires_grad=True)
+        TP.mlp(xc, pc, n_in, n_out, nh, 64, oa, half=half).backward(torch.tensor(g))
+        assert rel_l2(xt.grad.cpu().numpy(), xc.grad.numpy()) < tol, (half, 'dx')
+        assert rel_l2(gp, pc.grad.numpy()) < tol, (half, 'dparams')
     # padded output rows receive no gradient
     assert np.all(gp.reshape(-1)[-(16 - n_out) * 64:] == 0) if n_out < 16 else True
 
@@ -197,7 +199,7 @@ def test_field_forward_psnr_vs_fp32_restatement(O, dev):
     pts = (rng.random((50000, 3)) * 4 - 2).astype(np.float32)
     rgbs, _ = m(T(pts, dev), dirs=T(pts, dev))
     out_f, _, _ = O.field_forward(_oracle_params(O, ref), pts)
-    mse = float(np.mean((rgbs.cpu().numpy()[:, :3] - out_f[:, :3]) ** 2))
+    mse = float(np.mean((rgbs.detach().cpu().numpy()[:, :3] - out_f[:, :3]) ** 2))
     assert O.compute_psnr(mse) > 55.0
 
 
@@ -211,11 +213,13 @@ def test_field_backward(O, dev, dt, table_dtype):
     gr = rng.standard_normal((M, 8)).astype(np.float32)
     sig, rgbs = m.field(T(pts, dev), False)
     ((sig * T(gs, dev)).sum() + (rgbs * T(gr, dev)).sum()).backward()
-    out_r, sig_r = ref(torch.tensor(pts))
+    # reference: autograd through the PyTorch restatement with the same operand roundings emulated
+    # (straight-through), so the ReLU masks agree; see test_network_forward_backward for why
+    out_r, sig_r = ref(torch.tensor(pts), half=dt, table_half=table_dtype is None)
     ((sig_r[:, 0] * torch.tensor(gs)).sum() + (out_r * torch.tensor(gr)).sum()).backward()
     ga = m.arena.grad.cpu().numpy()
     gt = ga[:m.table_elems].reshape(m.rows, 2, 2)
-    tol = 2e-2 if dt == 'f16' else 5e-2
+    tol = 5e-3 if dt == 'f16' else 3e-2
     assert rel_l2(gt[:, 0, :], ref.emb_density.grad.numpy()) < tol
     assert rel_l2(gt[:, 1, :], ref.emb_color.grad.numpy()) < tol
     gm = ga[m.table_elems:]
