@@ -75,7 +75,12 @@ def cpu_baseline(budget_s, nc):
     # thread count: all host cores unless the (cgroup-limited) box runs faster on one -- calibrated on
     # a 250-ray chunk, the count actually used is what `cores` reports
     best = None
-    for nt in sorted({os.cpu_count() or 1, 1}, reverse=True):
+    try:
+        ncpu = len(os.sched_getaffinity(0))
+    except AttributeError:
+        ncpu = os.cpu_count() or 1
+    ncpu = max(1, min(ncpu, 16))      # the 1-GPU box's CPU share is 16 cores
+    for nt in sorted({ncpu, 1}, reverse=True):
         torch.set_num_threads(nt)
         one(slice(0, 250))
         _, t = one(slice(250, 500))

@@ -7,9 +7,12 @@
 //
 // wgrad needs the sample index on the MFMA k axis, i.e. every activation / gradient block
 // transposed.  That is done in registers with one 16x16x16 MFMA against the identity per block
-// (exact), not through LDS.  The 60 weight-gradient tiles (15360 fp32) are accumulated in LDS
-// (ds_add_f32) across all the tiles a workgroup processes and flushed with one global atomic
-// per weight per workgroup at the end.
+// (exact), not through LDS.  The 60 weight-gradient tiles (15360 fp32) live in the accumulator
+// half of the register file for the whole launch: workgroups are 4 waves = one wave per SIMD, so a
+// wave owns all 512 registers of its lane slice (240 of them these accumulators) and every wgrad
+// MFMA accumulates in place; each wave adds its tiles to grad_mlp once, at the end.
+// (A first version accumulated them in LDS with ds_add_f32: that alone cost 59 of 73 ms -- LDS
+// float atomics retire at well under one lane per clock -- see profiles/ and DESIGN.md.)
 //
 // Lane (s = lane&15, g = lane>>4) owns levels {2g, 2g+1, 8+2g, 9+2g} of sample s in both
 // directions, so dX arrives from the MFMA on the lane that scatters it.
@@ -27,9 +30,9 @@ constexpr int BW_D2T = 12288;    // d2^T  [64 x 16]  4 frag16
 constexpr int BW_D1T = 13312;    // d1^T  [32 x 64]  4 frag32
 constexpr int BW_TOTAL = 15360;
 
-constexpr int BWD_THREADS = 512;
-constexpr size_t BWD_QUEUE_BYTES_PER_WAVE = 192 * 16 + 192 * 4;
-constexpr size_t BWD_LDS_BYTES = (size_t)FW_TOTAL * 2 + (size_t)BW_TOTAL * 2 + (size_t)P_TOTAL * 4 + 16 * sizeof(NsrLevel) +
+constexpr int BWD_THREADS = 256;
+constexpr size_t BWD_QUEUE_BYTES_PER_WAVE = 1024 * 16 + 1024 * 4;
+constexpr size_t BWD_LDS_BYTES = (size_t)FW_TOTAL * 2 + (size_t)BW_TOTAL * 2 + 16 * sizeof(NsrLevel) +
                                  (BWD_THREADS / 64) * BWD_QUEUE_BYTES_PER_WAVE;
 
 struct FieldBwdArgs {
@@ -55,25 +58,34 @@ __device__ __forceinline__ void field_build_bw(short *lds, const float *__restri
     mm_build_frags<CD>(lds + BW_D1T, p + P_D1, 64, 32, 2, 64, true, 0, true);
 }
 
-// wgrad of one layer over this wave's 16 samples:
+// wgrad of one layer over this wave's 16 samples, accumulated in registers:
 //   dW[o][i] += sum_s G[o][s] * A[i][s]
-// Gt / At are the transposed blocks (lane = feature, elements = samples 4g+e).  Result tile
-// (ot,it): lane (i = lane&15, g) element e = dW[16ot + 4g + e][16it + i].  Rows are shifted by
-// row_shift and clipped to [row_lo, row_hi) (rows outside can only hold zeros).
+// Gt / At are the transposed blocks (lane = feature, elements = samples 4g+e).  Tile (ot,it) of
+// the result: lane (i = lane&15, g) element e = dW[16ot + 4g + e][16it + i].
 template <int CD, int NG, int NA>
-__device__ __forceinline__ void field_wgrad(float *lds_w, int in_p, int row_shift, int row_lo, int row_hi, const s4v (&Gt)[NG],
-                                            const s4v (&At)[NA], int lane) {
+__device__ __forceinline__ void field_wgrad(f4v (&acc)[NG * NA], const s4v (&Gt)[NG], const s4v (&At)[NA]) {
+#pragma unroll
+    for (int ot = 0; ot < NG; ot++) {
+#pragma unroll
+        for (int it = 0; it < NA; it++) acc[ot * NA + it] = MM<CD>::k16(Gt[ot], At[it], acc[ot * NA + it]);
+    }
+}
+
+// End of launch: one global atomic per weight per wave.  Rows are shifted by row_shift and clipped
+// to [0, row_hi) (rows outside hold zeros by construction: padded outputs get no gradient).
+template <int NG, int NA>
+__device__ __forceinline__ void field_wgrad_flush(float *__restrict__ gw, int in_p, int row_shift, int row_hi,
+                                                  const f4v (&acc)[NG * NA], int lane) {
     const int i = lane & 15, g = lane >> 4;
 #pragma unroll
     for (int ot = 0; ot < NG; ot++) {
 #pragma unroll
         for (int it = 0; it < NA; it++) {
-            f4v z = {0.f, 0.f, 0.f, 0.f};
-            const f4v d = MM<CD>::k16(Gt[ot], At[it], z);
 #pragma unroll
             for (int e = 0; e < 4; e++) {
                 const int row = 16 * ot + 4 * g + e - row_shift;
-                if (row >= row_lo && row < row_hi) atomicAdd(&lds_w[row * in_p + 16 * it + i], d[e]);
+                const float v = acc[ot * NA + it][e];
+                if (row >= 0 && row < row_hi && v != 0.0f) atomicAdd(gw + row * in_p + 16 * it + i, v);
             }
         }
     }
@@ -113,11 +125,16 @@ __device__ __forceinline__ void field_mask_pack(const f4v (&gacc)[4], const s8v 
 //   2. records {row, d0, d1, c0, c1} go through a small per-wave LDS queue and are drained 16 per
 //      wave-instruction with 4 lanes per record, so the four dwords of an interleaved row leave as
 //      ONE 16-byte request instead of four 4-byte ones.
-constexpr int SCQ_CAP = 192;     // records per wave; drained when >= SCQ_CAP - 64
+//   3. the queue is a RING drained in small paced bursts spread over the NEXT tile's compute
+//      (SCQ_PACE): atomics are fire-and-forget, but a burst of ~45 back-to-back wave-instructions
+//      blocks at issue once the memory side is saturated, and with one wave per SIMD a blocked
+//      wave is an idle SIMD.  Pacing lets the atomic service time hide under the MFMA/VALU work.
+constexpr int SCQ_CAP = 1024;    // records per wave (power of two)
+constexpr int SCQ_MASK = SCQ_CAP - 1;
 struct ScatterQueue {
     uint32_t *rows;              // [SCQ_CAP]
     float4 *vals;                // [SCQ_CAP]
-    int count;                   // wave-uniform
+    int head, tail;              // wave-uniform, monotonically increasing record indices
 };
 
 template <int K>
@@ -133,6 +150,7 @@ __device__ __forceinline__ uint32_t dpp_shl1_u(uint32_t v, uint32_t fill) {
     return (uint32_t)__builtin_amdgcn_update_dpp((int)fill, (int)v, 0x101, 0xF, 0xF, false);
 }
 
+// one Hillis-Steele step of a segmented inclusive scan over a 16-lane DPP row
 template <int K>
 __device__ __forceinline__ void seg_step(float4 &v, uint32_t &f) {
     const float a = dpp_shr_f<K>(v.x, 0.f), b = dpp_shr_f<K>(v.y, 0.f), c = dpp_shr_f<K>(v.z, 0.f), d = dpp_shr_f<K>(v.w, 0.f);
@@ -141,20 +159,26 @@ __device__ __forceinline__ void seg_step(float4 &v, uint32_t &f) {
     f |= fu;
 }
 
-__device__ __forceinline__ void scq_drain(ScatterQueue &q, float *__restrict__ gt, int lane, bool td, bool tc) {
+// Issues up to `max_instr` wave-instructions of 16 records (4 lanes per record: the 4 dwords of an
+// interleaved row leave as ONE 16-byte request).  Only full groups unless `flush`.
+__device__ __forceinline__ void scq_pace(ScatterQueue &q, float *__restrict__ gt, int lane, bool td, bool tc, int max_instr,
+                                         bool flush) {
     __builtin_amdgcn_wave_barrier();
     const int t = lane >> 2, i = lane & 3;
     const bool on = (i < 2) ? td : tc;
-    for (int base = 0; base < q.count; base += 16) {
-        const int rec = base + t;
-        if (rec < q.count && on) {
-            const uint32_t row = q.rows[rec];
-            const float v = reinterpret_cast<const float *>(q.vals)[rec * 4 + i];
+    for (int k = 0; k < max_instr; k++) {
+        const int avail = q.tail - q.head;
+        if (avail <= 0 || (avail < 16 && !flush)) break;
+        const int n = avail < 16 ? avail : 16;
+        if (t < n && on) {
+            const int slot = (q.head + t) & SCQ_MASK;
+            const uint32_t row = q.rows[slot];
+            const float v = reinterpret_cast<const float *>(q.vals)[slot * 4 + i];
             atomicAdd(gt + (size_t)row * 4 + i, v);
         }
+        q.head += n;
     }
     __builtin_amdgcn_wave_barrier();
-    q.count = 0;
 }
 
 // One level, all 8 corners, for the 16-sample tile (this lane = one sample of one level group).
@@ -177,7 +201,8 @@ __device__ __forceinline__ void field_scatter_level(const NsrLevel &lv, ScatterQ
             if ((idx & (1u << d)) == 0) { w *= 1 - f[d]; p[d] = c[d]; }
             else { w *= f[d]; p[d] = c[d] + 1; }
         }
-        // dead lanes get unique keys so they never merge with anything and never emit
+        // run = consecutive samples with the same table row; dead lanes get unique keys so they
+        // never merge with anything and never emit
         const uint32_t key = live ? lv.offset + nsr_grid_row(lv, p[0], p[1], p[2], 0u) : (0xFFFFFF00u | (uint32_t)lane);
         float4 v = live ? make_float4(w * gd0, w * gd1, w * gc0, w * gc1) : make_float4(0.f, 0.f, 0.f, 0.f);
         uint32_t head = (dpp_shr_u<1>(key, 0xFFFFFFFFu) != key) ? 1u : 0u;
@@ -188,13 +213,16 @@ __device__ __forceinline__ void field_scatter_level(const NsrLevel &lv, ScatterQ
         seg_step<8>(v, head);
         const bool push = tail && live;
         const unsigned long long mask = __ballot(push);
+        // make room first (rare: the paced drain keeps the ring nearly empty)
+        if (q.tail - q.head > SCQ_CAP - 64) scq_pace(q, gt, lane, td, tc, 8, false);
+        // records of one corner stay contiguous in the ring: consecutive samples of a ray step
+        // through x-neighbouring rows (the hash prime for x is 1), which the drain coalesces per line
         if (push) {
-            const int slot = q.count + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+            const int slot = (q.tail + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u))) & SCQ_MASK;
             q.rows[slot] = key;
             q.vals[slot] = v;
         }
-        q.count += (int)__popcll(mask);
-        if (q.count >= SCQ_CAP - 64) scq_drain(q, gt, lane, td, tc);
+        q.tail += (int)__popcll(mask);
     }
 }
 
@@ -204,12 +232,10 @@ k_field_bwd(FieldBwdArgs b) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     short *wl = reinterpret_cast<short *>(smem);
     short *wt = wl + FW_TOTAL;
-    float *wg = reinterpret_cast<float *>(smem + (size_t)(FW_TOTAL + BW_TOTAL) * 2);
-    NsrLevel *lds_lv = reinterpret_cast<NsrLevel *>(smem + (size_t)(FW_TOTAL + BW_TOTAL) * 2 + (size_t)P_TOTAL * 4);
+    NsrLevel *lds_lv = reinterpret_cast<NsrLevel *>(smem + (size_t)(FW_TOTAL + BW_TOTAL) * 2);
     const FieldArgs &a = b.f;
     field_build_fw<CD, false>(wl, a.params);
     field_build_bw<CD>(wt, a.params);
-    for (int i = threadIdx.x; i < P_TOTAL; i += BWD_THREADS) wg[i] = 0.0f;
     if (threadIdx.x < 16) lds_lv[threadIdx.x] = a.lv[threadIdx.x];
     __syncthreads();
 
@@ -227,28 +253,62 @@ k_field_bwd(FieldBwdArgs b) {
     const int nc = (int)b.nc;
     ScatterQueue q;
     {
-        char *qbase = smem + (size_t)(FW_TOTAL + BW_TOTAL) * 2 + (size_t)P_TOTAL * 4 + 16 * sizeof(NsrLevel) +
+        char *qbase = smem + (size_t)(FW_TOTAL + BW_TOTAL) * 2 + 16 * sizeof(NsrLevel) +
                       (size_t)wave * BWD_QUEUE_BYTES_PER_WAVE;
         q.vals = reinterpret_cast<float4 *>(qbase);
         q.rows = reinterpret_cast<uint32_t *>(qbase + SCQ_CAP * 16);
-        q.count = 0;
+        q.head = q.tail = 0;
     }
     const bool td = b.train_density != 0, tc = b.train_color != 0;
+    // weight-gradient accumulators (60 tiles x 4 regs), resident for the whole launch
+    f4v w_r3[4], w_r2[16], w_r1[4], w_c1b[4], w_c1a[8], w_k2[4], w_k1[8], w_d2[4], w_d1[8];
+    {
+        const f4v z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q4 = 0; q4 < 4; q4++) { w_r3[q4] = z; w_r1[q4] = z; w_c1b[q4] = z; w_k2[q4] = z; w_d2[q4] = z; }
+#pragma unroll
+        for (int q8 = 0; q8 < 8; q8++) { w_c1a[q8] = z; w_k1[q8] = z; w_d1[q8] = z; }
+#pragma unroll
+        for (int q16 = 0; q16 < 16; q16++) w_r2[q16] = z;
+    }
 
-    for (uint32_t tile = t_begin + wave; tile < t_end; tile += BWD_THREADS / 64) {
-        const uint32_t m = tile * 16 + s;
-        const bool valid = m < Mc;
-        float u0 = 0.f, u1 = 0.f, u2 = 0.f;
-        if (valid) {
-            u0 = field_unit(a.xyzs[(size_t)m * 3 + 0], a.bmin[0], a.bsize[0]);
-            u1 = field_unit(a.xyzs[(size_t)m * 3 + 1], a.bmin[1], a.bsize[1]);
-            u2 = field_unit(a.xyzs[(size_t)m * 3 + 2], a.bmin[2], a.bsize[2]);
+    // Software rotation: the gathers of tile t+1 are issued, waited for and interpolated BEFORE the
+    // atomics of tile t are issued.  vmcnt retires in order, so in the straightforward order the wait
+    // for the next tile's gather data also waits for every atomic of the previous tile (~3000+ cycles
+    // each under load) and the wave can never overlap its scatter with compute.
+    struct TileIn {
+        uint32_t m;
+        bool valid, live;
+        float u0, u1, u2;
+        s8v xd, xc;
+    };
+    auto load_tile = [&](uint32_t tile) {
+        TileIn r;
+        r.m = tile * 16 + s;
+        r.valid = r.m < Mc;
+        r.u0 = r.u1 = r.u2 = 0.f;
+        if (r.valid) {
+            r.u0 = field_unit(a.xyzs[(size_t)r.m * 3 + 0], a.bmin[0], a.bsize[0]);
+            r.u1 = field_unit(a.xyzs[(size_t)r.m * 3 + 1], a.bmin[1], a.bsize[1]);
+            r.u2 = field_unit(a.xyzs[(size_t)r.m * 3 + 2], a.bmin[2], a.bsize[2]);
         }
-        const bool live = valid && !(u0 < 0 || u0 > 1 || u1 < 0 || u1 > 1 || u2 < 0 || u2 > 1);
+        r.live = r.valid && !(r.u0 < 0 || r.u0 > 1 || r.u1 < 0 || r.u1 > 1 || r.u2 < 0 || r.u2 > 1);
+        field_encode<TT, CD, false>(lds_lv, tables, r.u0, r.u1, r.u2, r.live, g, r.xd, r.xc);
+        return r;
+    };
+    const uint32_t tstep = BWD_THREADS / 64;
+    TileIn cur;
+    if (t_begin + wave < t_end) cur = load_tile(t_begin + wave);
 
+    for (uint32_t tile = t_begin + wave; tile < t_end; tile += tstep) {
+        const uint32_t m = cur.m;
+        const bool valid = cur.valid, live = cur.live;
+        const float u0 = cur.u0, u1 = cur.u1, u2 = cur.u2;
+
+        // paced drain of the previous tile's records: SCQ_PACE(n) issues <= n atomic wave-instructions
+#define SCQ_PACE(n) scq_pace(q, b.grad_tables, lane, td, tc, (n), false)
         // ================= recompute forward, keeping rounded activations ====================
-        s8v xd[1], xc[1];
-        field_encode<TT, CD, false>(lds_lv, tables, u0, u1, u2, live, g, xd[0], xc[0]);
+        s8v xd[1] = {cur.xd}, xc[1] = {cur.xc};
         f4v h[4];
         s8v hd[2], hk[2], hc[2], hr1[2], hr2[2];
         f4v logit[1], c1[1], rgb[1];
@@ -263,8 +323,10 @@ k_field_bwd(FieldBwdArgs b) {
         const s4v c1b = mm_round4<CD, false>(c1[0]);
         mm_layer16<CD, 4>(wl + FW_R1, lane, c1b, h);
         mm_pack64<CD, true>(h, hr1);
+        SCQ_PACE(4);
         mm_layer32<CD, 4, 2>(wl + FW_R2, lane, hr1, h);
         mm_pack64<CD, true>(h, hr2);
+        SCQ_PACE(4);
         mm_layer32<CD, 1, 2>(wl + FW_R3, lane, hr2, rgb);
 
         // ================= upstream gradients in B-fragment form (row = 4g + e) ===============
@@ -312,12 +374,15 @@ k_field_bwd(FieldBwdArgs b) {
             field_tr4<CD>(hr2, ident, hr2t);
             field_tr4<CD>(g2, ident, g2t);
             const s4v dyrt[1] = {mm_transpose16<CD>(dyr, ident)};
-            field_wgrad<CD, 1, 4>(wg + P_R3, 64, 0, 0, 3, dyrt, hr2t, lane);
+            field_wgrad<CD, 1, 4>(w_r3, dyrt, hr2t);
+            SCQ_PACE(4);
             field_tr4<CD>(hr1, ident, hr1t);
-            field_wgrad<CD, 4, 4>(wg + P_R2, 64, 0, 0, 64, g2t, hr1t, lane);
+            field_wgrad<CD, 4, 4>(w_r2, g2t, hr1t);
+            SCQ_PACE(4);
             field_tr4<CD>(g1, ident, g1t);
             const s4v c1t[1] = {mm_transpose16<CD>(c1b, ident)};
-            field_wgrad<CD, 4, 1>(wg + P_R1, 16, 0, 0, 64, g1t, c1t, lane);
+            field_wgrad<CD, 4, 1>(w_r1, g1t, c1t);
+            SCQ_PACE(4);
         }
         // transposed encoder features (shared by the color1 / class / density wgrads)
         s4v xct[2], xdt[2];
@@ -334,9 +399,11 @@ k_field_bwd(FieldBwdArgs b) {
             mm_layer32<CD, 2, 2>(wt + BW_C1AT, lane, gh, gxc);
             field_tr4<CD>(hc, ident, hct);
             const s4v gc1t[1] = {mm_transpose16<CD>(gc1, ident)};
-            field_wgrad<CD, 1, 4>(wg + P_C1B, 64, 0, 0, 16, gc1t, hct, lane);
+            field_wgrad<CD, 1, 4>(w_c1b, gc1t, hct);
+            SCQ_PACE(4);
             field_tr4<CD>(gh, ident, ght);
-            field_wgrad<CD, 4, 2>(wg + P_C1A, 32, 0, 0, 64, ght, xct, lane);
+            field_wgrad<CD, 4, 2>(w_c1a, ght, xct);
+            SCQ_PACE(4);
         }
         {
             s8v gh[2];
@@ -346,9 +413,11 @@ k_field_bwd(FieldBwdArgs b) {
             mm_layer32_acc<CD, 2, 2>(wt + BW_K1T, lane, gh, gxc);
             field_tr4<CD>(hk, ident, hkt);
             const s4v dykt[1] = {mm_transpose16<CD>(dyk, ident)};
-            field_wgrad<CD, 1, 4>(wg + P_K2, 64, CLASS_ROW_SHIFT, 0, nc, dykt, hkt, lane);
+            field_wgrad<CD, 1, 4>(w_k2, dykt, hkt);
+            SCQ_PACE(4);
             field_tr4<CD>(gh, ident, ght);
-            field_wgrad<CD, 4, 2>(wg + P_K1, 32, 0, 0, 64, ght, xct, lane);
+            field_wgrad<CD, 4, 2>(w_k1, ght, xct);
+            SCQ_PACE(4);
         }
         // ================= density: 32 -> 64 -> 1 =============================================
         f4v gxd[2];
@@ -360,14 +429,20 @@ k_field_bwd(FieldBwdArgs b) {
             mm_layer32<CD, 2, 2>(wt + BW_D1T, lane, gh, gxd);
             field_tr4<CD>(hd, ident, hdt);
             const s4v dydt[1] = {mm_transpose16<CD>(dyd, ident)};
-            field_wgrad<CD, 1, 4>(wg + P_D2, 64, 0, 0, 1, dydt, hdt, lane);
+            field_wgrad<CD, 1, 4>(w_d2, dydt, hdt);
+            SCQ_PACE(4);
             field_tr4<CD>(gh, ident, ght);
-            field_wgrad<CD, 4, 2>(wg + P_D1, 32, 0, 0, 64, ght, xdt, lane);
+            field_wgrad<CD, 4, 2>(w_d1, ght, xdt);
+            SCQ_PACE(4);
         }
 
         // ================= table scatter =======================================================
         // gxd[t][2*(i&1)+f] is d L / d feature f of level lvl[i] (t = i >> 1): same lane<->level map
         // as the forward encode.
+        // next tile's gathers first (see above), then this tile's scatter
+        SCQ_PACE(4);
+        if (tile + tstep < t_end) cur = load_tile(tile + tstep);
+        SCQ_PACE(4);
         if (td || tc) {
             const int lvl[4] = {2 * g, 2 * g + 1, 8 + 2 * g, 9 + 2 * g};
 #pragma unroll
@@ -379,15 +454,20 @@ k_field_bwd(FieldBwdArgs b) {
             }
         }
     }
-    if (td || tc) scq_drain(q, b.grad_tables, lane, td, tc);
+    if (td || tc) scq_pace(q, b.grad_tables, lane, td, tc, 1 << 20, true);
 
-    // ---- flush the workgroup's weight gradients ---------------------------------------------------
-    __syncthreads();
+    // ---- flush this wave's weight gradients -------------------------------------------------------
     if (b.grad_mlp) {
-        for (int i = threadIdx.x; i < P_TOTAL; i += BWD_THREADS) {
-            const float v = wg[i];
-            if (v != 0.0f) atomicAdd(b.grad_mlp + i, v);
-        }
+        float *gm = b.grad_mlp;
+        field_wgrad_flush<1, 4>(gm + P_R3, 64, 0, 3, w_r3, lane);
+        field_wgrad_flush<4, 4>(gm + P_R2, 64, 0, 64, w_r2, lane);
+        field_wgrad_flush<4, 1>(gm + P_R1, 16, 0, 64, w_r1, lane);
+        field_wgrad_flush<1, 4>(gm + P_C1B, 64, 0, 16, w_c1b, lane);
+        field_wgrad_flush<4, 2>(gm + P_C1A, 32, 0, 64, w_c1a, lane);
+        field_wgrad_flush<1, 4>(gm + P_K2, 64, CLASS_ROW_SHIFT, nc, w_k2, lane);
+        field_wgrad_flush<4, 2>(gm + P_K1, 32, 0, 64, w_k1, lane);
+        field_wgrad_flush<1, 4>(gm + P_D2, 64, 0, 1, w_d2, lane);
+        field_wgrad_flush<4, 2>(gm + P_D1, 32, 0, 64, w_d1, lane);
     }
 }
 
@@ -405,10 +485,10 @@ int nsr_field_backward(const nsr_field_desc *desc, const void *tables, const flo
     const int st = field_fill_args(desc, b.f, M, nblocks);
     if (st != NSR_OK) return st;
     if ((uintptr_t)tables & 15u) return NSR_ERR_INVALID_ARG;
-    // one 512-thread workgroup per CU (120.5 KiB of LDS): at most 256 resident, each walks a
-    // contiguous range of tiles
+    // 4-wave workgroups, one wave per SIMD (each wave needs the 512-register budget): one
+    // workgroup per CU is resident, each walks a contiguous range of tiles
     const uint32_t ntiles = (M + 15) / 16;
-    nblocks = (ntiles + 7) / 8;
+    nblocks = (ntiles + 3) / 4;
     if (nblocks > 256) nblocks = 256;
     b.f.tiles_per_block = (ntiles + nblocks - 1) / nblocks;
     b.f.tables = tables; b.f.params = mlp_params; b.f.xyzs = xyzs; b.f.m_dev = m_dev; b.f.sigmas = nullptr; b.f.rgbs = nullptr;
