@@ -193,17 +193,43 @@ def main():
         # ---- roofline of the dominant kernel ------------------------------------------------
         dom = max(prof.items(), key=lambda kv: kv[1][1])[0] if prof else None
         tb = 2 if args.table_dtype == 'f16' else 4
-        # algorithmic bytes per sample (SURVEY 8d / DESIGN.md): gather = 2 enc x 16 lvl x 8 corners x 2 feat x tb;
-        # backward = the same gather again (recompute) + read-modify-write of the fp32 gradient rows (2 x 2048 B)
-        bytes_per_sample = {'field_fwd': 256 * tb, 'field_bwd': 256 * tb + 2 * 256 * 4}
+        # algorithmic bytes per sample (SURVEY 8d / DESIGN.md): gather = 2 enc x 16 lvl x 8 corners x 2 feat x tb
+        # = 512 x tb; backward = the same gather again (recompute) + read-modify-write of the same 512
+        # fp32 gradient elements (2 x 2048 B)
+        bytes_per_sample = {'field_fwd': 512 * tb, 'field_bwd': 512 * tb + 2 * 512 * 4}
         roofline = None
-        if dom in bytes_per_sample:
-            launches, tot_ms, avg_ms = prof[dom]
-            per_launch = bytes_per_sample[dom] * samples / max(launches, 1)
+        # HBM traffic per launch from the PMC passes of profiles/ (separate rocprofv3 --pmc FETCH_SIZE /
+        # --pmc WRITE_SIZE runs of this same command, corrected as MI355X_MICROARCH.md prescribes);
+        # scaled by the sample count of this run, null when the profile does not match the configuration
+        traffic_per_sample = {}
+        try:
+            with open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')) as f:
+                pm = json.load(f)
+            if args.table_dtype == 'f16' and args.compute_dtype == 'f16':
+                traffic_per_sample = {k[2:]: v['traffic_bytes_per_sample'] for k, v in pm['kernels'].items()}
+        except (OSError, KeyError, ValueError):
+            pass
+
+        def roof(name):
+            launches, tot_ms, avg_ms = prof[name]
+            per_launch = bytes_per_sample[name] * samples / max(launches, 1)
             ach = per_launch / (avg_ms * 1e-3) / 1e9
-            roofline = {'bound': 'hbm', 'kernel': 'k_' + dom, 'achieved': round(ach, 1), 'peak': 8000.0, 'unit': 'GB/s',
-                        'frac': round(ach / 8000.0, 4), 'traffic': None,
-                        'avg_launch_ms': round(avg_ms, 4), 'algorithmic_bytes_per_sample': bytes_per_sample[dom]}
+            tr = traffic_per_sample.get(name)
+            return {'bound': 'hbm', 'kernel': 'k_' + name, 'achieved': round(ach, 1), 'peak': 8000.0, 'unit': 'GB/s',
+                    'frac': round(ach / 8000.0, 4),
+                    'traffic': None if tr is None else int(tr * samples / max(launches, 1)),
+                    'avg_launch_ms': round(avg_ms, 4), 'algorithmic_bytes_per_sample': bytes_per_sample[name]}
+        if dom in bytes_per_sample:
+            roofline = roof(dom)
+        extra = {}
+        if 'field_fwd' in prof:
+            extra['hash_gather_fwd'] = roof('field_fwd')
+            launches, tot_ms, avg_ms = prof['field_fwd']
+            flops = 2.0 * (12544 + 64 * nc) * samples / max(launches, 1)      # SURVEY 8d, no padding counted
+            tf = flops / (avg_ms * 1e-3) / 1e12
+            extra['mlp_mfma_fwd'] = {'bound': 'mfma', 'kernel': 'k_field_fwd', 'achieved': round(tf, 1), 'peak': 2500.0,
+                                     'unit': 'TFLOP/s', 'frac': round(tf / 2500.0, 4),
+                                     'note': 'MLP FLOPs of the fused kernel over its whole duration (gather-bound kernel)'}
         result = {
             'metric': 'train Mrays/sec', 'value': round(value, 4), 'unit': 'Mrays/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True,
@@ -218,6 +244,7 @@ def main():
             },
             'kernel_ms_per_step': {k: round(v[1] / args.steps, 4) for k, v in sorted(prof.items())},
             'roofline': roofline,
+            'rooflines_other': extra,
         }
         print('[bench] gpu leg done: ' + json.dumps(result), file=sys.stderr, flush=True)
         if world == 1 and not args.no_cpu_baseline:

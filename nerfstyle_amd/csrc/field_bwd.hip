@@ -211,7 +211,9 @@ __device__ __forceinline__ void field_scatter_level(const NsrLevel &lv, ScatterQ
         seg_step<2>(v, head);
         seg_step<4>(v, head);
         seg_step<8>(v, head);
-        const bool push = tail && live;
+        // a run whose summed gradient is exactly zero (e.g. samples behind an opaque surface: the
+        // composite backward gives them zero gradient) adds nothing: skip its request
+        const bool push = tail && live && (v.x != 0.f || v.y != 0.f || v.z != 0.f || v.w != 0.f);
         const unsigned long long mask = __ballot(push);
         // make room first (rare: the paced drain keeps the ring nearly empty)
         if (q.tail - q.head > SCQ_CAP - 64) scq_pace(q, gt, lane, td, tc, 8, false);
