@@ -329,107 +329,109 @@ k_march_emit(const float *__restrict__ rays_o, const float *__restrict__ rays_d,
 // ---------------------------------------------------------------------------------------------
 #define RM_MAXC 16
 
+// Training composite, coalesced form.  The reference runs one thread per ray over [M, C] arrays
+// (raymarching.cu:806-879, 904-986): every load of a wave touches 64 different lines (measured
+// 221 / 282 B of HBM traffic per sample against ~56 algorithmic).  Here a ray is owned by a group
+// of LPR lanes (LPR = 4, 8 or 16 >= C), lane c of the group owns channel c: the group's rgbs /
+// grad_rgbs access of a sample is one contiguous C*4-byte piece, sigma / deltas are a broadcast
+// address, consecutive steps walk consecutive memory.  The scalar recurrences (T, ws, depth) are
+// evaluated redundantly by every lane of the group, in the reference's operation order.
+
 // raymarching.cu:806-879
+template <int LPR>
 __global__ void __launch_bounds__(RM_BLOCK)
 k_composite_train_fwd(const float *__restrict__ sigmas, const float *__restrict__ rgbs, const float *__restrict__ deltas,
                       const int32_t *__restrict__ rays, uint32_t M, uint32_t N, uint32_t C, float T_thresh, int is_ndc,
                       float *__restrict__ weights_sum, float *__restrict__ depth, float *__restrict__ image) {
-    const uint32_t n = blockIdx.x * RM_BLOCK + threadIdx.x;
+    const uint32_t tid = blockIdx.x * RM_BLOCK + threadIdx.x;
+    const uint32_t n = tid / LPR, ch = tid % LPR;
     if (n >= N) return;
     const uint32_t index = (uint32_t)rays[n * 3], offset = (uint32_t)rays[n * 3 + 1], num_steps = (uint32_t)rays[n * 3 + 2];
-    float acc[RM_MAXC];
-#pragma unroll
-    for (int i = 0; i < RM_MAXC; i++) acc[i] = 0.0f;
+    const bool has_ch = ch < C;
+    float acc = 0.0f;
     float T = 1.0f, ws = 0.0f, t = 0.0f, d = 0.0f;
     if (!(num_steps == 0 || offset + num_steps >= M)) {
         const float *s = sigmas + offset;
-        const float *rgb = rgbs + (size_t)offset * C;
+        const float *rgb = rgbs + (size_t)offset * C + (has_ch ? ch : 0);
         const float *dl = deltas + (size_t)offset * 4;
         for (uint32_t step = 0; step < num_steps; step++) {
-            const float alpha = 1.0f - __expf(-s[step] * (is_ndc ? dl[step * 4 + 2] : dl[step * 4 + 0]));
+            const float2 dd = is_ndc ? *reinterpret_cast<const float2 *>(dl + step * 4 + 2) : *reinterpret_cast<const float2 *>(dl + step * 4);
+            const float alpha = 1.0f - __expf(-s[step] * dd.x);
             const float weight = alpha * T;
-#pragma unroll
-            for (int i = 0; i < RM_MAXC; i++)
-                if ((uint32_t)i < C) acc[i] += weight * rgb[(size_t)step * C + i];
-            t += (is_ndc ? dl[step * 4 + 3] : dl[step * 4 + 1]);
+            if (has_ch) acc += weight * rgb[(size_t)step * C];
+            t += dd.y;
             d += weight * t;
             ws += weight;
             T *= 1.0f - alpha;
             if (T < T_thresh) break;   // :862
         }
     }
-    weights_sum[index] = ws;
-    depth[index] = d;
-#pragma unroll
-    for (int i = 0; i < RM_MAXC; i++)
-        if ((uint32_t)i < C) image[(size_t)index * C + i] = acc[i];
+    if (ch == 0) {
+        weights_sum[index] = ws;
+        depth[index] = d;
+    }
+    if (has_ch) image[(size_t)index * C + ch] = acc;
 }
 
-// raymarching.cu:904-986.  rgbs_buf lives in registers.
+// raymarching.cu:904-986.  rgbs_buf lives in registers (one channel per lane).
+template <int LPR>
 __global__ void __launch_bounds__(RM_BLOCK)
 k_composite_train_bwd(const float *__restrict__ grad_weights_sum, const float *__restrict__ grad_image,
                       const float *__restrict__ sigmas, const float *__restrict__ rgbs, const float *__restrict__ deltas,
                       const int32_t *__restrict__ rays, int is_ndc, const float *__restrict__ weights_sum,
                       const float *__restrict__ image, uint32_t M, uint32_t N, uint32_t C, float T_thresh,
                       float *__restrict__ grad_sigmas, float *__restrict__ grad_rgbs, int zero_fill) {
-    const uint32_t n = blockIdx.x * RM_BLOCK + threadIdx.x;
-    if (n >= N) return;
-    const uint32_t index = (uint32_t)rays[n * 3], offset = (uint32_t)rays[n * 3 + 1], num_steps = (uint32_t)rays[n * 3 + 2];
-    if (num_steps == 0) return;
-    if (offset + num_steps >= M) {
+    const uint32_t tid = blockIdx.x * RM_BLOCK + threadIdx.x;
+    // whole lane groups must stay converged for the cross-lane sums below: no early return
+    const uint32_t n = min(tid / LPR, N - 1), ch = tid % LPR;
+    const bool ray_ok = tid / LPR < N;
+    const uint32_t index = (uint32_t)rays[n * 3], offset = (uint32_t)rays[n * 3 + 1];
+    const uint32_t num_steps = ray_ok ? (uint32_t)rays[n * 3 + 2] : 0u;
+    const bool has_ch = ch < C;
+    const bool dropped = offset + num_steps >= M;
+    float *gs = grad_sigmas + offset;
+    float *grgb = grad_rgbs + (size_t)offset * C + (has_ch ? ch : 0);
+    if (num_steps != 0 && dropped) {
         // dropped ray (:929): the reference leaves its pre-zeroed gradients untouched; write the
         // zeros here (inside the buffer only) so that callers need no memset of [M, 1 + C]
         if (zero_fill) {
             for (uint32_t step = 0; step < num_steps && offset + step < M; step++) {
-                grad_sigmas[offset + step] = 0.0f;
-                for (uint32_t i = 0; i < C; i++) grad_rgbs[(size_t)(offset + step) * C + i] = 0.0f;
+                if (ch == 0) gs[step] = 0.0f;
+                if (has_ch) grgb[(size_t)step * C] = 0.0f;
             }
         }
-        return;
     }
-    float buf[RM_MAXC], gim[RM_MAXC], im[RM_MAXC];
-#pragma unroll
-    for (int i = 0; i < RM_MAXC; i++) {
-        buf[i] = 0.0f;
-        gim[i] = (uint32_t)i < C ? grad_image[(size_t)index * C + i] : 0.0f;
-        im[i] = (uint32_t)i < C ? image[(size_t)index * C + i] : 0.0f;
-    }
-    const float gws = grad_weights_sum[index];
-    const float ws_final = weights_sum[index];
+    const uint32_t steps = dropped ? 0u : num_steps;
+    const float gim = (has_ch && steps) ? grad_image[(size_t)index * C + ch] : 0.0f;
+    const float im = (has_ch && steps) ? image[(size_t)index * C + ch] : 0.0f;
+    const float gws = steps ? grad_weights_sum[index] : 0.0f;
+    const float ws_final = steps ? weights_sum[index] : 0.0f;
     const float *s = sigmas + offset;
-    const float *rgb = rgbs + (size_t)offset * C;
+    const float *rgb = rgbs + (size_t)offset * C + (has_ch ? ch : 0);
     const float *dl = deltas + (size_t)offset * 4;
-    float *gs = grad_sigmas + offset;
-    float *grgb = grad_rgbs + (size_t)offset * C;
-    float T = 1.0f;
+    float buf = 0.0f, T = 1.0f;
+    // lanes of a group run the same trip count (same ray), different groups of a wave do not: the
+    // cross-lane sum uses DPP-free shuffles restricted to the group, executed by every live group
     uint32_t step = 0;
-    for (; step < num_steps; step++) {
+    for (; step < steps; step++) {
         const float delta = is_ndc ? dl[step * 4 + 2] : dl[step * 4 + 0];
         const float alpha = 1.0f - __expf(-s[step] * delta);
         const float weight = alpha * T;
-        float c[RM_MAXC];
-#pragma unroll
-        for (int i = 0; i < RM_MAXC; i++) {
-            c[i] = (uint32_t)i < C ? rgb[(size_t)step * C + i] : 0.0f;
-            buf[i] += weight * c[i];
-        }
+        const float c = has_ch ? rgb[(size_t)step * C] : 0.0f;
+        buf += weight * c;
         T *= 1.0f - alpha;
         if (T < T_thresh) break;   // :961
-        float gsum = 0.0f;
+        if (has_ch) grgb[(size_t)step * C] = gim * weight;
+        float gsum = has_ch ? gim * (T * c - (im - buf)) : 0.0f;
 #pragma unroll
-        for (int i = 0; i < RM_MAXC; i++) {
-            if ((uint32_t)i < C) {
-                grgb[(size_t)step * C + i] = gim[i] * weight;
-                gsum += gim[i] * (T * c[i] - (im[i] - buf[i]));
-            }
-        }
-        gs[step] = delta * (gsum + gws * (1 - ws_final));
+        for (int off = LPR / 2; off >= 1; off >>= 1) gsum += __shfl_xor(gsum, off, LPR);
+        if (ch == 0) gs[step] = delta * (gsum + gws * (1 - ws_final));
     }
     // samples at and after the early stop keep the zero gradient the reference pre-fills
     if (zero_fill) {
-        for (; step < num_steps; step++) {
-            gs[step] = 0.0f;
-            for (uint32_t i = 0; i < C; i++) grgb[(size_t)step * C + i] = 0.0f;
+        for (; step < steps; step++) {
+            if (ch == 0) gs[step] = 0.0f;
+            if (has_ch) grgb[(size_t)step * C] = 0.0f;
         }
     }
 }
@@ -692,8 +694,13 @@ int nsr_composite_rays_train_forward(const float *sigmas, const float *rgbs, con
     NSR_CHECK_PTR(sigmas); NSR_CHECK_PTR(rgbs); NSR_CHECK_PTR(deltas); NSR_CHECK_PTR(rays);
     NSR_CHECK_PTR(weights_sum); NSR_CHECK_PTR(depth); NSR_CHECK_PTR(image);
     if (C == 0 || C > RM_MAXC) return NSR_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(k_composite_train_fwd, dim3(nsr_div_up(N, RM_BLOCK)), dim3(RM_BLOCK), 0, (hipStream_t)stream, sigmas,
-                       rgbs, deltas, rays, M, N, C, T_thresh, is_ndc, weights_sum, depth, image);
+    hipStream_t hs = (hipStream_t)stream;
+    if (((uintptr_t)deltas & 7u) != 0) return NSR_ERR_INVALID_ARG;
+#define NSR_CF(LPR)                                                                                              \
+    hipLaunchKernelGGL((k_composite_train_fwd<LPR>), dim3(nsr_div_up((uint64_t)N * LPR, RM_BLOCK)), dim3(RM_BLOCK), 0, hs, \
+                       sigmas, rgbs, deltas, rays, M, N, C, T_thresh, is_ndc, weights_sum, depth, image)
+    if (C <= 4) NSR_CF(4); else if (C <= 8) NSR_CF(8); else NSR_CF(16);
+#undef NSR_CF
     return nsr_launch_status();
 }
 
@@ -706,9 +713,13 @@ int nsr_composite_rays_train_backward(const float *grad_weights_sum, const float
     NSR_CHECK_PTR(deltas); NSR_CHECK_PTR(rays); NSR_CHECK_PTR(weights_sum); NSR_CHECK_PTR(image);
     NSR_CHECK_PTR(grad_sigmas); NSR_CHECK_PTR(grad_rgbs);
     if (C == 0 || C > RM_MAXC) return NSR_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(k_composite_train_bwd, dim3(nsr_div_up(N, RM_BLOCK)), dim3(RM_BLOCK), 0, (hipStream_t)stream,
-                       grad_weights_sum, grad_image, sigmas, rgbs, deltas, rays, is_ndc, weights_sum, image, M, N, C, T_thresh,
-                       grad_sigmas, grad_rgbs, 1);
+    hipStream_t hs = (hipStream_t)stream;
+#define NSR_CB(LPR)                                                                                              \
+    hipLaunchKernelGGL((k_composite_train_bwd<LPR>), dim3(nsr_div_up((uint64_t)N * LPR, RM_BLOCK)), dim3(RM_BLOCK), 0, hs, \
+                       grad_weights_sum, grad_image, sigmas, rgbs, deltas, rays, is_ndc, weights_sum, image, M, N, C, T_thresh, \
+                       grad_sigmas, grad_rgbs, 1)
+    if (C <= 4) NSR_CB(4); else if (C <= 8) NSR_CB(8); else NSR_CB(16);
+#undef NSR_CB
     return nsr_launch_status();
 }
 
