@@ -155,7 +155,8 @@ template <int K>
 __device__ __forceinline__ void seg_step(float4 &v, uint32_t &f) {
     const float a = dpp_shr_f<K>(v.x, 0.f), b = dpp_shr_f<K>(v.y, 0.f), c = dpp_shr_f<K>(v.z, 0.f), d = dpp_shr_f<K>(v.w, 0.f);
     const uint32_t fu = dpp_shr_u<K>(f, 1u);      // lanes shifted in from outside the row count as heads
-    if (!f) { v.x += a; v.y += b; v.z += c; v.w += d; }
+    const float m = f ? 0.0f : 1.0f;              // branchless: a 4-add body is cheaper than an exec-mask branch
+    v.x = fmaf(a, m, v.x); v.y = fmaf(b, m, v.y); v.z = fmaf(c, m, v.z); v.w = fmaf(d, m, v.w);
     f |= fu;
 }
 

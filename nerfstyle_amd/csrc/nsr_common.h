@@ -31,6 +31,10 @@ struct NsrLevel {
     uint32_t use_hash;    // gridencoder.cu:75
     uint32_t mul[3];      // dense-index strides (0 for dims the loop at :62-66 never reaches)
     uint32_t style_mul;   // :68-71
+    // index % size without a division (Granlund & Montgomery, "Division by invariant integers using
+    // multiplication", fig. 4.1): q = (t + ((n - t) >> sh1)) >> sh2 with t = mulhi(magic, n); exact for
+    // every 32-bit n and every size >= 1, powers of two included -> one branchless path
+    uint32_t magic, sh1, sh2, pad_;
 };
 struct NsrLevels {
     NsrLevel lv[NSR_MAX_LEVELS];
@@ -57,6 +61,12 @@ static inline void nsr_fill_levels(NsrLevels *out, const int32_t *offsets, uint3
             stride *= 512u;
         }
         v.use_hash = (gridtype == 0 && stride > v.size) ? 1u : 0u;
+        uint32_t lg = 0;
+        while ((1ull << lg) < (unsigned long long)v.size) lg++;        // lg = ceil(log2(size))
+        v.magic = v.size ? (uint32_t)((((1ull << lg) - v.size) << 32) / v.size + 1ull) : 0u;
+        v.sh1 = lg < 1 ? lg : 1;
+        v.sh2 = lg > 0 ? lg - 1 : 0;
+        v.pad_ = 0;
     }
 }
 
@@ -70,8 +80,9 @@ __device__ __forceinline__ uint32_t nsr_grid_row(const NsrLevel &lv, uint32_t x,
     } else {
         index = x * lv.mul[0] + y * lv.mul[1] + z * lv.mul[2] + style * lv.style_mul;
     }
-    // hashmap sizes are powers of two on the capped levels; '%' on the rest
-    return ((lv.size & (lv.size - 1)) == 0) ? (index & (lv.size - 1)) : (index % lv.size);
+    const uint32_t t = __umulhi(lv.magic, index);
+    const uint32_t q = (t + ((index - t) >> lv.sh1)) >> lv.sh2;
+    return index - q * lv.size;                                       // == index % lv.size
 }
 
 // gridencoder.cu:138-149.  Contraction is disabled so floor() sees the same value as the oracle.
