@@ -127,6 +127,15 @@ int nsr_composite_rays(uint32_t n_alive, uint32_t n_step, float T_thresh, int32_
                        uint32_t C, int is_ndc, float *weights_sum, float *depth, float *image,
                        nsr_stream_t stream);
 
+/* Single-pass inference composite (no reference counterpart as one call): kernel_composite_rays'
+ * arithmetic (raymarching.cu:1133-1231: T = 1 - weight_sum, stop test before the sample, absolute t
+ * from nears[ray]) over the compacted samples [offset, offset+count) that nsr_march_rays_train
+ * emits -- replaces the host loop of up to max_steps march_rays / composite_rays iterations
+ * (renderer.py:266-285).  Outputs are written (not accumulated). */
+int nsr_composite_rays_infer(const float *sigmas, const float *rgbs, const float *deltas, const int32_t *rays,
+                             const float *nears, uint32_t M, uint32_t N, uint32_t C, float T_thresh,
+                             float *weights_sum, float *depth, float *image, nsr_stream_t stream);
+
 /* Alive-ray compaction on the device (replaces the boolean-mask `rays_alive[rays_alive >= 0]`
  * of renderer.py:284, which is a host sync): stable, ballot/scan based.
  * out [n_alive] i32, n_out [1] i32 (device).  workspace: nsr_compact_alive_workspace_bytes(n). */

@@ -52,6 +52,7 @@ SIGNATURES = {
     'nsr_march_rays': (i32, [u32, u32, vp, vp, vp, vp, vp, f32, f32, u32, i32, u32, u32, vp, vp, vp, vp, vp, vp, vp,
                              vp]),
     'nsr_composite_rays': (i32, [u32, u32, f32, vp, vp, vp, vp, vp, u32, i32, vp, vp, vp, vp]),
+    'nsr_composite_rays_infer': (i32, [vp, vp, vp, vp, vp, u32, u32, u32, f32, vp, vp, vp, vp]),
     'nsr_compact_alive_workspace_bytes': (u64, [u32]),
     'nsr_compact_alive': (i32, [vp, u32, vp, vp, vp, vp]),
     'nsr_grid_resolutions': (i32, [u32, f32, u32, ctypes.POINTER(ctypes.c_uint32)]),

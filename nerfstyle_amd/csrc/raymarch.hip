@@ -436,6 +436,45 @@ k_composite_train_bwd(const float *__restrict__ grad_weights_sum, const float *_
     }
 }
 
+// Single-pass inference composite: the arithmetic of kernel_composite_rays (raymarching.cu:1133-1231)
+// -- T = 1 - weight_sum, stop test on T BEFORE the sample (:1206), absolute t starting at near --
+// applied to the compacted [offset, offset+count) samples of the training-style march instead of
+// up to 1024 host-driven march_rays / composite_rays iterations (renderer.py:266-285).
+template <int LPR>
+__global__ void __launch_bounds__(RM_BLOCK)
+k_composite_infer(const float *__restrict__ sigmas, const float *__restrict__ rgbs, const float *__restrict__ deltas,
+                  const int32_t *__restrict__ rays, const float *__restrict__ nears, uint32_t M, uint32_t N, uint32_t C,
+                  float T_thresh, float *__restrict__ weights_sum, float *__restrict__ depth, float *__restrict__ image) {
+    const uint32_t tid = blockIdx.x * RM_BLOCK + threadIdx.x;
+    const uint32_t n = tid / LPR, ch = tid % LPR;
+    if (n >= N) return;
+    const uint32_t index = (uint32_t)rays[n * 3], offset = (uint32_t)rays[n * 3 + 1], num_steps = (uint32_t)rays[n * 3 + 2];
+    const bool has_ch = ch < C;
+    float acc = 0.0f, ws = 0.0f, d = 0.0f;
+    if (!(num_steps == 0 || offset + num_steps >= M)) {
+        float t_phy = nears[index];
+        const float *s = sigmas + offset;
+        const float *rgb = rgbs + (size_t)offset * C + (has_ch ? ch : 0);
+        const float *dl = deltas + (size_t)offset * 4;
+        for (uint32_t step = 0; step < num_steps; step++) {
+            const float2 dd = *reinterpret_cast<const float2 *>(dl + step * 4);
+            const float alpha = 1.0f - __expf(-s[step] * dd.x);
+            const float T = 1 - ws;
+            const float weight = alpha * T;
+            ws += weight;
+            t_phy += dd.y;
+            d += weight * t_phy;
+            if (has_ch) acc += weight * rgb[(size_t)step * C];
+            if (T < T_thresh) break;   // :1206
+        }
+    }
+    if (ch == 0) {
+        weights_sum[index] = ws;
+        depth[index] = d;
+    }
+    if (has_ch) image[(size_t)index * C + ch] = acc;
+}
+
 // ---------------------------------------------------------------------------------------------
 // inference march / composite (raymarching.cu:1004-1120, 1133-1231)
 // ---------------------------------------------------------------------------------------------
@@ -748,6 +787,23 @@ int nsr_composite_rays(uint32_t n_alive, uint32_t n_step, float T_thresh, int32_
     if (C == 0 || C > RM_MAXC) return NSR_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(k_composite_rays, dim3(nsr_div_up(n_alive, RM_BLOCK)), dim3(RM_BLOCK), 0, (hipStream_t)stream, n_alive,
                        n_step, T_thresh, rays_alive, rays_t, sigmas, rgbs, deltas, C, is_ndc, weights_sum, depth, image);
+    return nsr_launch_status();
+}
+
+int nsr_composite_rays_infer(const float *sigmas, const float *rgbs, const float *deltas, const int32_t *rays, const float *nears,
+                             uint32_t M, uint32_t N, uint32_t C, float T_thresh, float *weights_sum, float *depth, float *image,
+                             nsr_stream_t stream) {
+    if (N == 0) return NSR_OK;
+    NSR_CHECK_PTR(sigmas); NSR_CHECK_PTR(rgbs); NSR_CHECK_PTR(deltas); NSR_CHECK_PTR(rays); NSR_CHECK_PTR(nears);
+    NSR_CHECK_PTR(weights_sum); NSR_CHECK_PTR(depth); NSR_CHECK_PTR(image);
+    if (C == 0 || C > RM_MAXC) return NSR_ERR_UNSUPPORTED;
+    if (((uintptr_t)deltas & 7u) != 0) return NSR_ERR_INVALID_ARG;
+    hipStream_t hs = (hipStream_t)stream;
+#define NSR_CI(LPR)                                                                                                 \
+    hipLaunchKernelGGL((k_composite_infer<LPR>), dim3(nsr_div_up((uint64_t)N * LPR, RM_BLOCK)), dim3(RM_BLOCK), 0, hs, \
+                       sigmas, rgbs, deltas, rays, nears, M, N, C, T_thresh, weights_sum, depth, image)
+    if (C <= 4) NSR_CI(4); else if (C <= 8) NSR_CI(8); else NSR_CI(16);
+#undef NSR_CI
     return nsr_launch_status();
 }
 

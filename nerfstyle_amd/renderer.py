@@ -175,6 +175,35 @@ class Renderer(torch.nn.Module):
     # ---- inference render ----------------------------------------------------------------------
     @torch.no_grad()
     def render_test(self, rays: RayBatch, **kwargs):
+        """renderer.py:237-293.  By default ONE march + ONE fused field launch + ONE composite with the
+        inference kernel's arithmetic (nsr_composite_rays_infer) instead of up to max_steps host
+        iterations; `self.reference_inference_loop = True` selects the reference's loop structure
+        (render_test_loop), which the tests hold equal to this path."""
+        if getattr(self, 'reference_inference_loop', False):
+            return self.render_test_loop(rays, **kwargs)
+        from . import _lib as L
+        nears, fars = raymarching.near_far_from_aabb(rays.origins, rays.dirs, self.aabb, self.cfg.min_near)
+        N = rays.origins.shape[0]
+        M = self.sample_capacity(N)
+        counter = torch.zeros(2, dtype=torch.int32, device=self.device)
+        xyzs, _, deltas, rays_info = raymarching.march_rays_train_nosync(
+            rays.origins, rays.dirs, self.bound, self.density_bitfield, self.cascade, self.cfg.grid_size, nears, fars,
+            M, counter, 0., self.cfg.max_steps)
+        sigmas, rgbs = self.model.field(xyzs, sigma_only=False, m_dev=counter, density_scale=self.cfg.density_scale)
+        C = self.raymarch_channels
+        weights_sum = torch.empty(N, dtype=torch.float32, device=self.device)
+        depth = torch.empty(N, dtype=torch.float32, device=self.device)
+        image = torch.empty(N, C, dtype=torch.float32, device=self.device)
+        L.check(L.lib().nsr_composite_rays_infer(L.p(sigmas), L.p(rgbs), L.p(deltas), L.p(rays_info), L.p(nears), M, N, C,
+                                                 float(self.cfg.t_thresh), L.p(weights_sum), L.p(depth), L.p(image),
+                                                 L.stream()), 'composite_rays_infer')
+        classes = image[:, 3:]
+        image = image[:, :3] + (1 - weights_sum).unsqueeze(-1)
+        depth = torch.clamp(depth - nears, min=0) / (fars - nears)
+        return image, depth, classes
+
+    @torch.no_grad()
+    def render_test_loop(self, rays: RayBatch, **kwargs):
         """renderer.py:237-293.  Same iteration structure (n_step = max(min(N // n_alive, 8), 1));
         alive-ray compaction is a device scan instead of boolean-mask indexing."""
         nears, fars = raymarching.near_far_from_aabb(rays.origins, rays.dirs, self.aabb, self.cfg.min_near)

@@ -66,6 +66,25 @@ def test_render_train_matches_oracle_pipeline(O, dev):
     assert np.abs(out['trans_map'].detach().cpu().numpy()[ok] - d_o[ok]).max() < 5e-3
 
 
+def test_single_pass_inference_equals_reference_loop(O, dev):
+    """render_test (one march + one field launch + nsr_composite_rays_infer) against the reference's
+    iteration structure (render_test_loop: march_rays / composite_rays / compaction per step), with
+    early termination active (opaque scene)."""
+    from nerfstyle_amd.common import Box2D
+    r, ref, poses, intr, bits = _setup(dev)
+    r.cfg.density_scale = 400.0                 # opaque boxes -> rays terminate early (T < 1e-4)
+    pose = torch.tensor(poses[5], device=dev)
+    patch = Box2D(100, 60, 256, 200)
+    fast = r.render(pose, None, patch=patch, training=False)
+    r.reference_inference_loop = True
+    loop = r.render(pose, None, patch=patch, training=False)
+    for k in ('rgb_map', 'classes'):
+        assert float((fast[k] - loop[k]).abs().max()) < 2e-4, k
+    ok = torch.isfinite(loop['trans_map'])
+    assert float((fast['trans_map'][ok] - loop['trans_map'][ok]).abs().max()) < 2e-3
+    assert float(loop['rgb_map'].min()) < 0.9        # something was rendered
+
+
 def test_render_test_matches_render_train(O, dev):
     """Inference loop (march_rays / composite_rays / compaction) vs the training path on a
     200x200 patch: same samples, T = 1 - ws vs running product, stop test one sample later."""
