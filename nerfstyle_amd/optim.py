@@ -100,3 +100,44 @@ class FusedAdam:
 def exp_lr(initial_lr, it, decay_steps):
     """trainers/base.py:223-227: lr = initial * 0.1 ** (it / learning_rate_decay)"""
     return initial_lr * (0.1 ** (it / decay_steps)) if decay_steps > 0 else initial_lr
+
+
+class LossScaler:
+    """Dynamic loss scaling with torch.cuda.amp.GradScaler's policy (trainers/base.py:228,420-425:
+    init 65536, x2 after 2000 clean steps, x0.5 and skip the step on inf/nan), for the f16 MFMA path:
+    with f16 operands the gradients of a mean-over-rays loss underflow unscaled (the reference trains
+    tcnn's fp16 networks under GradScaler for the same reason).  bf16 compute needs no scaling.
+
+        loss = scaler.scale(loss); loss.backward(); stepped = scaler.step(opt)
+
+    The inf/nan check is one reduction over the flat gradient arena and one host read per step."""
+
+    def __init__(self, init_scale=65536.0, growth_factor=2.0, backoff_factor=0.5, growth_interval=2000, enabled=True):
+        self.scale_value = float(init_scale) if enabled else 1.0
+        self.growth_factor, self.backoff_factor, self.growth_interval = growth_factor, backoff_factor, growth_interval
+        self.enabled = enabled
+        self._good_steps = 0
+
+    def scale(self, loss):
+        return loss * self.scale_value
+
+    def get_scale(self):
+        return self.scale_value
+
+    def step(self, opt: FusedAdam) -> bool:
+        if not self.enabled:
+            opt.step()
+            return True
+        g = opt.model._ensure_grad()
+        finite = bool(torch.isfinite(g.abs().max()).item())
+        if finite:
+            opt.step(grad_scale=self.scale_value)
+            self._good_steps += 1
+            if self._good_steps >= self.growth_interval:
+                self.scale_value *= self.growth_factor
+                self._good_steps = 0
+            return True
+        g.zero_()
+        self.scale_value *= self.backoff_factor
+        self._good_steps = 0
+        return False

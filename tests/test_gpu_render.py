@@ -194,3 +194,51 @@ def test_update_state_matches_oracle_restatement(O, dev, monkeypatch):
     out = r.render(torch.tensor(poses[0], device=dev), None, num_rays=None, training=True,
                    pix_subset=torch.arange(0, 4096, device=dev))
     assert torch.isfinite(out['rgb_map']).all()
+
+
+def test_deferred_backprop_equals_direct_and_trains_only_colour_table(O, dev):
+    """Stylisation glue (trainers/style.py:162-204): per-patch deferred back-propagation gives the
+    gradient of one direct full-frame backward; with OPTIM_KEYS = ['x_color_embedder'] (style.py:25)
+    only the colour table moves."""
+    from nerfstyle_amd.common import Intrinsics
+    from nerfstyle_amd.optim import FusedAdam
+    from nerfstyle_amd.stylize import deferred_backprop_step, patch_list
+    r, ref, poses, intr, bits = _setup(dev, cap=256)
+    r.intr = Intrinsics(96, 128, intr.fx * 128 / intr.w, intr.fy * 128 / intr.w, 64., 48.)    # small frame
+    pose = torch.tensor(poses[2], device=dev)
+    g = torch.Generator().manual_seed(3)
+    target = torch.rand(96, 128, 3, generator=g).to(dev)
+    kern = torch.ones(3, 1, 5, 5, device=dev) / 25.0
+
+    def image_loss(rgb):            # a stand-in for VGG features: box-blurred image vs target
+        x = rgb.permute(2, 0, 1).unsqueeze(0)
+        t = target.permute(2, 0, 1).unsqueeze(0)
+        return ((torch.nn.functional.conv2d(x, kern, padding=2, groups=3) -
+                 torch.nn.functional.conv2d(t, kern, padding=2, groups=3)) ** 2).mean()
+
+    assert len(patch_list(128, 96, 50)) == 6
+    m = r.model
+    opt = FusedAdam(m, lr=0.1, keywords=['x_color_embedder'])      # cfgs/training/style.yaml:1
+    assert m.train_color_table and not m.train_density_table
+    # f16 MFMA operands: gradients of a mean-over-pixels loss underflow without loss scaling; the
+    # reference trains under GradScaler (init scale 65536, trainers/base.py:228) for the same reason
+    SCALE = 65536.0
+    loss, _ = deferred_backprop_step(r, pose, image_loss, patch_size=50, loss_scale=SCALE)
+    g_def = m.arena.grad.clone()
+    m.arena.grad.zero_()
+    out = r.render(pose, None, training=True)
+    (image_loss(out['rgb_map'].view(96, 128, 3)) * SCALE).backward()
+    g_dir = m.arena.grad.clone()
+    assert float(g_dir.abs().sum()) > 0
+    assert rel_l2(g_def.cpu().numpy(), g_dir.cpu().numpy()) < 2e-3
+    gt = g_dir[:m.table_elems].view(m.rows, 2, 2)
+    assert float(gt[:, 0, :].abs().max()) == 0.0                     # density table not scattered
+    assert float(gt[:, 1, :].abs().max()) > 0.0
+    before = m.arena.detach().clone()
+    opt.step(grad_scale=SCALE)
+    after = m.arena.detach()
+    tb, ta = before[:m.table_elems].view(m.rows, 2, 2), after[:m.table_elems].view(m.rows, 2, 2)
+    assert torch.equal(tb[:, 0, :], ta[:, 0, :])                     # density table untouched
+    assert torch.equal(before[m.table_elems:], after[m.table_elems:])  # MLPs untouched
+    assert not torch.equal(tb[:, 1, :], ta[:, 1, :])                 # colour table moved
+    assert float(m.arena.grad.abs().max()) == 0.0
