@@ -31,7 +31,7 @@ constexpr int BW_D1T = 13312;    // d1^T  [32 x 64]  4 frag32
 constexpr int BW_TOTAL = 15360;
 
 constexpr int BWD_THREADS = 256;
-constexpr size_t BWD_QUEUE_BYTES_PER_WAVE = 1024 * 16 + 1024 * 4;
+constexpr size_t BWD_QUEUE_BYTES_PER_WAVE = 1024 * 16 + 1024 * 4 + 512 * 8;
 constexpr size_t BWD_LDS_BYTES = (size_t)FW_TOTAL * 2 + (size_t)BW_TOTAL * 2 + 16 * sizeof(NsrLevel) +
                                  (BWD_THREADS / 64) * BWD_QUEUE_BYTES_PER_WAVE;
 
@@ -131,9 +131,12 @@ __device__ __forceinline__ void field_mask_pack(const f4v (&gacc)[4], const s8v 
 //      wave is an idle SIMD.  Pacing lets the atomic service time hide under the MFMA/VALU work.
 constexpr int SCQ_CAP = 1024;    // records per wave (power of two)
 constexpr int SCQ_MASK = SCQ_CAP - 1;
+constexpr int SCQ_SEEN = 512;    // direct-mapped "row -> record still in the ring" table per wave
 struct ScatterQueue {
     uint32_t *rows;              // [SCQ_CAP]
     float4 *vals;                // [SCQ_CAP]
+    uint32_t *seen_row;          // [SCQ_SEEN] last row pushed under this hash
+    int *seen_idx;               // [SCQ_SEEN] its (monotonic) record index
     int head, tail;              // wave-uniform, monotonically increasing record indices
 };
 
@@ -214,16 +217,33 @@ __device__ __forceinline__ void field_scatter_level(const NsrLevel &lv, ScatterQ
         seg_step<8>(v, head);
         // a run whose summed gradient is exactly zero (e.g. samples behind an opaque surface: the
         // composite backward gives them zero gradient) adds nothing: skip its request
-        const bool push = tail && live && (v.x != 0.f || v.y != 0.f || v.z != 0.f || v.w != 0.f);
-        const unsigned long long mask = __ballot(push);
+        bool push = tail && live && (v.x != 0.f || v.y != 0.f || v.z != 0.f || v.w != 0.f);
         // make room first (rare: the paced drain keeps the ring nearly empty)
         if (q.tail - q.head > SCQ_CAP - 64) scq_pace(q, gt, lane, td, tc, 8, false);
+        // Exact duplicate addresses are the one thing the atomic path never merges (tools/
+        // atomic_merge_rule.hip), and they are common: face-adjacent cells share 4 of their 8 corner rows,
+        // runs continue across tiles.  If this row was pushed recently and its record is still in the
+        // ring, add into that record instead of emitting another request.
+        const uint32_t hsh = (key * 2654435761u) >> (32 - 9);
+        if (push) {
+            const uint32_t r = q.seen_row[hsh];
+            const int j = q.seen_idx[hsh];
+            if (r == key && (uint32_t)(j - q.head) < (uint32_t)(q.tail - q.head)) {
+                float *dst = reinterpret_cast<float *>(q.vals + (j & SCQ_MASK));
+                atomicAdd(dst + 0, v.x); atomicAdd(dst + 1, v.y); atomicAdd(dst + 2, v.z); atomicAdd(dst + 3, v.w);
+                push = false;
+            }
+        }
+        const unsigned long long mask = __ballot(push);
         // records of one corner stay contiguous in the ring: consecutive samples of a ray step
         // through x-neighbouring rows (the hash prime for x is 1), which the drain coalesces per line
         if (push) {
-            const int slot = (q.tail + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u))) & SCQ_MASK;
+            const int idxr = q.tail + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+            const int slot = idxr & SCQ_MASK;
             q.rows[slot] = key;
             q.vals[slot] = v;
+            q.seen_row[hsh] = key;
+            q.seen_idx[hsh] = idxr;
         }
         q.tail += (int)__popcll(mask);
     }
@@ -260,6 +280,9 @@ k_field_bwd(FieldBwdArgs b) {
                       (size_t)wave * BWD_QUEUE_BYTES_PER_WAVE;
         q.vals = reinterpret_cast<float4 *>(qbase);
         q.rows = reinterpret_cast<uint32_t *>(qbase + SCQ_CAP * 16);
+        q.seen_row = reinterpret_cast<uint32_t *>(qbase + SCQ_CAP * 20);
+        q.seen_idx = reinterpret_cast<int *>(qbase + SCQ_CAP * 20 + SCQ_SEEN * 4);
+        for (int k = lane; k < SCQ_SEEN; k += 64) { q.seen_row[k] = 0xFFFFFFFFu; q.seen_idx[k] = -1; }
         q.head = q.tail = 0;
     }
     const bool td = b.train_density != 0, tc = b.train_color != 0;
