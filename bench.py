@@ -110,11 +110,16 @@ def cpu_baseline(budget_s, nc):
 def main():
     args = parse()
     from nerfstyle_amd import parallel as P
-    rank, local_rank, world = P.init()
-    assert world == args.gpus, 'launch with torchrun --nproc-per-node {} (WORLD_SIZE={})'.format(args.gpus, world)
+    # rehearsal knobs (NOT used by the driver): run N ranks on ONE GPU over gloo to exercise the N > 1
+    # code path on a 1-GPU box -- NSR_BENCH_BACKEND=gloo NSR_BENCH_DEVICE=0
+    backend = os.environ.get('NSR_BENCH_BACKEND')
+    rank, local_rank, world = P.env_world()
     assert torch.cuda.is_available(), 'bench.py needs a HIP device (no CPU fallback for the product path)'
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
+    dev_index = int(os.environ.get('NSR_BENCH_DEVICE', local_rank))
+    torch.cuda.set_device(dev_index)
+    rank, local_rank, world = P.init(backend)
+    assert world == args.gpus, 'launch with torchrun --nproc-per-node {} (WORLD_SIZE={})'.format(args.gpus, world)
+    dev = torch.device('cuda', dev_index)
 
     from nerfstyle_amd import profiling, raymarching
     from nerfstyle_amd.common import BBox

@@ -28,7 +28,7 @@ def init(backend=None):
             backend = 'nccl' if torch.cuda.is_available() else 'gloo'
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
-        if backend == 'nccl':
+        if backend == 'nccl' and 'NSR_BENCH_DEVICE' not in os.environ:
             torch.cuda.set_device(local_rank)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local_rank, world
