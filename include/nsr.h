@@ -220,10 +220,13 @@ typedef struct nsr_field_desc {
 /* xyzs [M,3] f32 world positions.  sigmas [M] f32 = exp(logit) * density_scale;
  * rgbs [M, 3+nc] f32 = cat(sigmoid(rgb), classes) or NULL for the sigma-only branch
  * (style_nerf.py:125-126).  m_dev: optional device int32 sample count (<= M) -- tiles past it
- * are skipped, so callers can size M as a capacity and never read the count on the host. */
+ * are skipped, so callers can size M as a capacity and never read the count on the host.
+ * feats (optional, may be NULL): ceil(M/16)*2048 bytes that receive the encoded features of both
+ * encoders as ready-made MFMA B fragments (128 B per sample, the only thing a training forward
+ * saves); pass the same buffer to nsr_field_backward to skip its re-gather. */
 int nsr_field_forward(const nsr_field_desc *desc, const void *tables, const float *mlp_params,
                       const float *xyzs, uint32_t M, const int32_t *m_dev, float *sigmas, float *rgbs,
-                      nsr_stream_t stream);
+                      void *feats, nsr_stream_t stream);
 
 /* grad_sigmas [M], grad_rgbs [M,3+nc] f32.  Recomputes the forward (nothing saved), then
  * back-propagates: trunc_exp' = exp(clamp(logit,-15,15)) (tcnn_nerf.py:62-66), sigmoid', ReLU
@@ -234,7 +237,8 @@ int nsr_field_forward(const nsr_field_desc *desc, const void *tables, const floa
 int nsr_field_backward(const nsr_field_desc *desc, const void *tables, const float *mlp_params,
                        const float *xyzs, uint32_t M, const int32_t *m_dev, const float *grad_sigmas,
                        const float *grad_rgbs, float *grad_tables, float *grad_mlp,
-                       int train_density_table, int train_color_table, nsr_stream_t stream);
+                       int train_density_table, int train_color_table, const void *feats,
+                       nsr_stream_t stream);
 
 /* fp32 master tables -> f16 gather copy (the reference's `embeddings.to(torch.half)` under
  * autocast, grid.py:42-43).  n = number of scalars. */

@@ -45,6 +45,11 @@ k_field_fwd(FieldArgs a) {
         const bool live = valid && !(u0 < 0 || u0 > 1 || u1 < 0 || u1 > 1 || u2 < 0 || u2 > 1);
         s8v xd, xc;
         field_encode<TT, CD, SIGMA_ONLY>(lds_lv, tables, u0, u1, u2, live, g, xd, xc);
+        if (!SIGMA_ONLY && a.feats) {
+            s8v *fo = reinterpret_cast<s8v *>(a.feats) + ((size_t)tile * 64 + lane) * 2;
+            fo[0] = xd;
+            fo[1] = xc;
+        }
 
         // ---- density net: 32 -> 64 -> 1 ----------------------------------------------------
         f4v h[4];
@@ -123,7 +128,7 @@ static int field_launch_fwd(const FieldArgs &a, uint32_t nblocks, bool sigma_onl
 extern "C" {
 
 int nsr_field_forward(const nsr_field_desc *desc, const void *tables, const float *mlp_params, const float *xyzs, uint32_t M,
-                      const int32_t *m_dev, float *sigmas, float *rgbs, nsr_stream_t stream) {
+                      const int32_t *m_dev, float *sigmas, float *rgbs, void *feats, nsr_stream_t stream) {
     if (M == 0) return NSR_OK;
     NSR_CHECK_PTR(desc); NSR_CHECK_PTR(tables); NSR_CHECK_PTR(mlp_params); NSR_CHECK_PTR(xyzs); NSR_CHECK_PTR(sigmas);
     FieldArgs a;
@@ -133,6 +138,8 @@ int nsr_field_forward(const nsr_field_desc *desc, const void *tables, const floa
     if ((uintptr_t)tables & 15u) return NSR_ERR_INVALID_ARG;
     if (rgbs && a.C_ch == 8 && ((uintptr_t)rgbs & 15u)) return NSR_ERR_INVALID_ARG;
     a.tables = tables; a.params = mlp_params; a.xyzs = xyzs; a.m_dev = m_dev; a.sigmas = sigmas; a.rgbs = rgbs;
+    a.feats = feats;
+    if (feats && ((uintptr_t)feats & 15u)) return NSR_ERR_INVALID_ARG;
     const bool so = rgbs == nullptr;
     hipStream_t s = (hipStream_t)stream;
     if (desc->table_dtype == NSR_F32 && desc->compute_dtype == NSR_F16) return field_launch_fwd<float, NSR_F16>(a, nblocks, so, s);

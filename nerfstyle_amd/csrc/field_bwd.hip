@@ -298,15 +298,18 @@ k_field_bwd(FieldBwdArgs b) {
         for (int q16 = 0; q16 < 16; q16++) w_r2[q16] = z;
     }
 
-    // Software rotation: the gathers of tile t+1 are issued, waited for and interpolated BEFORE the
-    // atomics of tile t are issued.  vmcnt retires in order, so in the straightforward order the wait
-    // for the next tile's gather data also waits for every atomic of the previous tile (~3000+ cycles
-    // each under load) and the wave can never overlap its scatter with compute.
+    // Software rotation around the in-order vmcnt counter: a tile's records are pushed to the LDS ring
+    // by its (atomic-free) scatter phase, the next tile's inputs are loaded right after it, and the
+    // atomics are issued by pace points inside the NEXT tile's dgrad / wgrad section, where no load
+    // result is consumed.  In the straightforward order every load-use waits for a full trip of
+    // freshly issued atomics to the memory-side atomic unit (41 % of the wave's cycles, SQ_WAIT_ANY).
     struct TileIn {
         uint32_t m;
         bool valid, live;
         float u0, u1, u2;
         s8v xd, xc;
+        float gsig;        // grad_sigmas[m] (used by the g == 0 lanes)
+        float grgb[4];     // grad_rgbs[m, 4g .. 4g+3]
     };
     auto load_tile = [&](uint32_t tile) {
         TileIn r;
@@ -319,7 +322,35 @@ k_field_bwd(FieldBwdArgs b) {
             r.u2 = field_unit(a.xyzs[(size_t)r.m * 3 + 2], a.bmin[2], a.bsize[2]);
         }
         r.live = r.valid && !(r.u0 < 0 || r.u0 > 1 || r.u1 < 0 || r.u1 > 1 || r.u2 < 0 || r.u2 > 1);
-        field_encode<TT, CD, false>(lds_lv, tables, r.u0, r.u1, r.u2, r.live, g, r.xd, r.xc);
+        // every global load of the tile is issued HERE, in one group, after the atomic-free scatter
+        // phase of the previous tile: a load placed after a pace point would wait (vmcnt retires in
+        // order, and the compiler can only use vmcnt(0) around the dynamic pace loops) for atomics
+        // issued a few cycles earlier, i.e. for a full trip to the memory-side atomic unit
+        r.gsig = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; e++) r.grgb[e] = 0.f;
+        if (r.valid) {
+            r.gsig = b.grad_sigmas[r.m];
+            const float *gp = b.grad_rgbs + (size_t)r.m * a.C_ch;
+            if (a.C_ch == 8) {
+                if (g < 2) {
+                    const float4 t4 = reinterpret_cast<const float4 *>(gp)[g];
+                    r.grgb[0] = t4.x; r.grgb[1] = t4.y; r.grgb[2] = t4.z; r.grgb[3] = t4.w;
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; e++)
+                    if ((uint32_t)(4 * g + e) < a.C_ch) r.grgb[e] = gp[4 * g + e];
+            }
+        }
+        if (a.feats) {
+            // the forward saved this lane's two B fragments: two 16-byte loads instead of 32 gathers
+            const s8v *fi = reinterpret_cast<const s8v *>(a.feats) + ((size_t)tile * 64 + lane) * 2;
+            r.xd = fi[0];
+            r.xc = fi[1];
+        } else {
+            field_encode<TT, CD, false>(lds_lv, tables, r.u0, r.u1, r.u2, r.live, g, r.xd, r.xc);
+        }
         return r;
     };
     const uint32_t tstep = BWD_THREADS / 64;
@@ -330,6 +361,8 @@ k_field_bwd(FieldBwdArgs b) {
         const uint32_t m = cur.m;
         const bool valid = cur.valid, live = cur.live;
         const float u0 = cur.u0, u1 = cur.u1, u2 = cur.u2;
+        const float cur_gsig = cur.gsig;
+        const float cur_grgb[4] = {cur.grgb[0], cur.grgb[1], cur.grgb[2], cur.grgb[3]};
 
         // paced drain of the previous tile's records: SCQ_PACE(n) issues <= n atomic wave-instructions
 #define SCQ_PACE(n) scq_pace(q, b.grad_tables, lane, td, tc, (n), false)
@@ -363,14 +396,13 @@ k_field_bwd(FieldBwdArgs b) {
                 if (g == 0) {
                     // sigma = exp(logit) * density_scale; trunc_exp backward clamps (tcnn_nerf.py:62-66)
                     const float x = logit[0][0];
-                    gd[0] = b.grad_sigmas[m] * a.density_scale * expf(fminf(fmaxf(x, -15.0f), 15.0f));
+                    gd[0] = cur_gsig * a.density_scale * expf(fminf(fmaxf(x, -15.0f), 15.0f));
                 }
-                const float *gp = b.grad_rgbs + (size_t)m * a.C_ch;
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
                     const int ch = 4 * g + e;
                     if ((uint32_t)ch < a.C_ch) {
-                        const float gv = gp[ch];
+                        const float gv = cur_grgb[e];
                         if (ch < 3) {
                             const float sg = field_sigmoid(rgb[0][e]);
                             gr[e] = gv * sg * (1.0f - sg);
@@ -465,10 +497,8 @@ k_field_bwd(FieldBwdArgs b) {
         // ================= table scatter =======================================================
         // gxd[t][2*(i&1)+f] is d L / d feature f of level lvl[i] (t = i >> 1): same lane<->level map
         // as the forward encode.
-        // next tile's gathers first (see above), then this tile's scatter
-        SCQ_PACE(4);
-        if (tile + tstep < t_end) cur = load_tile(tile + tstep);
-        SCQ_PACE(4);
+        // this tile's scatter: VALU + LDS only (records go to the ring; atomics are issued by the pace
+        // points of the NEXT tile's dgrad / wgrad section), then the next tile's loads
         if (td || tc) {
             const int lvl[4] = {2 * g, 2 * g + 1, 8 + 2 * g, 9 + 2 * g};
 #pragma unroll
@@ -479,6 +509,7 @@ k_field_bwd(FieldBwdArgs b) {
                                     lane, td, tc);
             }
         }
+        if (tile + tstep < t_end) cur = load_tile(tile + tstep);
     }
     if (td || tc) scq_pace(q, b.grad_tables, lane, td, tc, 1 << 20, true);
 
@@ -501,7 +532,8 @@ extern "C" {
 
 int nsr_field_backward(const nsr_field_desc *desc, const void *tables, const float *mlp_params, const float *xyzs, uint32_t M,
                        const int32_t *m_dev, const float *grad_sigmas, const float *grad_rgbs, float *grad_tables,
-                       float *grad_mlp, int train_density_table, int train_color_table, nsr_stream_t stream) {
+                       float *grad_mlp, int train_density_table, int train_color_table, const void *feats,
+                       nsr_stream_t stream) {
     if (M == 0) return NSR_OK;
     NSR_CHECK_PTR(desc); NSR_CHECK_PTR(tables); NSR_CHECK_PTR(mlp_params); NSR_CHECK_PTR(xyzs);
     NSR_CHECK_PTR(grad_sigmas); NSR_CHECK_PTR(grad_rgbs);
@@ -518,6 +550,8 @@ int nsr_field_backward(const nsr_field_desc *desc, const void *tables, const flo
     if (nblocks > 256) nblocks = 256;
     b.f.tiles_per_block = (ntiles + nblocks - 1) / nblocks;
     b.f.tables = tables; b.f.params = mlp_params; b.f.xyzs = xyzs; b.f.m_dev = m_dev; b.f.sigmas = nullptr; b.f.rgbs = nullptr;
+    b.f.feats = const_cast<void *>(feats);
+    if (feats && ((uintptr_t)feats & 15u)) return NSR_ERR_INVALID_ARG;
     b.grad_sigmas = grad_sigmas; b.grad_rgbs = grad_rgbs; b.grad_tables = grad_tables; b.grad_mlp = grad_mlp;
     b.train_density = train_density_table; b.train_color = train_color_table; b.nc = desc->num_classes;
     hipStream_t s = (hipStream_t)stream;

@@ -31,6 +31,7 @@ struct FieldArgs {
     uint32_t M;
     float *sigmas;
     float *rgbs;
+    void *feats;          // optional [ntiles][64 lanes][2] x 16 B: (xd, xc) B fragments per lane
     float bmin[3], bsize[3];
     float density_scale;
     uint32_t C_ch;

@@ -82,10 +82,15 @@ class _field(Function):
         rgbs = None if sigma_only else torch.empty(M, model.out_channels, dtype=torch.float32, device=dev)
         desc = model._desc(density_scale)
         tables = model._gather_tables()
+        # the one thing a training forward saves: the encoded features as MFMA fragments (128 B/sample)
+        feats = None
+        if (not sigma_only) and model.save_features and torch.is_grad_enabled() and arena.requires_grad:
+            feats = torch.empty(((M + 15) // 16) * 512, dtype=torch.int32, device=dev)
         with profiling.timed('field_fwd_sigma' if sigma_only else 'field_fwd'):
             L.check(L.lib().nsr_field_forward(ctypes.byref(desc), L.p(tables), L.p(model._mlp_flat()),
-                                              L.p(xyzs), M, L.p(m_dev), L.p(sigmas), L.p(rgbs), L.stream()),
+                                              L.p(xyzs), M, L.p(m_dev), L.p(sigmas), L.p(rgbs), L.p(feats), L.stream()),
                     'field_forward')
+        ctx.feats = feats
         ctx.model = model
         ctx.m_dev = m_dev
         ctx.density_scale = density_scale
@@ -115,7 +120,7 @@ class _field(Function):
             L.check(L.lib().nsr_field_backward(
                 ctypes.byref(desc), L.p(tables), L.p(model._mlp_flat()), L.p(xyzs), M, L.p(ctx.m_dev),
                 L.p(grad_sigmas), L.p(grad_rgbs), L.p(ga), ga.data_ptr() + model.table_elems * 4,
-                int(model.train_density_table), int(model.train_color_table), L.stream()), 'field_backward')
+                int(model.train_density_table), int(model.train_color_table), L.p(ctx.feats), L.stream()), 'field_backward')
         return None, None, None, None, None, None
 
 
@@ -172,6 +177,7 @@ class StyleTCNerf(nn.Module):
         self.table_dtype = torch.float16 if enc_dtype in (None, torch.float16) else torch.float32
         self.train_density_table = True
         self.train_color_table = True
+        self.save_features = True     # forward keeps 128 B/sample of encoded features for the backward
 
         max_bound = torch.max(bbox.size).item()
         template = get_grid_encoder(cfg, max_bound)

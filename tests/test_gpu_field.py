@@ -233,6 +233,13 @@ def test_field_backward(O, dev, dt, table_dtype):
     sig, rgbs = m.field(T(pts, dev), False)
     ((sig * T(gs, dev)).sum() + (rgbs * T(gr, dev)).sum()).backward()
     assert rel_l2(m.arena.grad.cpu().numpy(), 2 * ga) < 1e-3
+    # the backward with saved encoder features (default) == the backward that re-gathers
+    m.arena.grad.zero_()
+    m.save_features = False
+    sig, rgbs = m.field(T(pts, dev), False)
+    ((sig * T(gs, dev)).sum() + (rgbs * T(gr, dev)).sum()).backward()
+    assert rel_l2(m.arena.grad.cpu().numpy(), ga) < 1e-3
+    m.save_features = True
     # stylisation mode: only the colour table is trained (trainers/style.py:25)
     m.arena.grad.zero_()
     m.train_density_table = False
