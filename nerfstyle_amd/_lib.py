@@ -9,7 +9,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libnsr_hip.so')
+LIB_PATH = os.environ.get('NSR_LIB_PATH') or os.path.join(_HERE, 'libnsr_hip.so')   # override: ablation builds (tools/)
 
 NSR_F32, NSR_F16, NSR_BF16 = 0, 1, 2
 NSR_ACT_NONE, NSR_ACT_SIGMOID = 0, 1

@@ -16,6 +16,7 @@
 //
 // Lane (s = lane&15, g = lane>>4) owns levels {2g, 2g+1, 8+2g, 9+2g} of sample s in both
 // directions, so dX arrives from the MFMA on the lane that scatters it.
+#include <stdio.h>
 #include "field_common.h"
 
 // ---- backward LDS image (units: shorts) ------------------------------------------------------
@@ -43,6 +44,7 @@ struct FieldBwdArgs {
     float *grad_mlp;
     int train_density, train_color;
     uint32_t nc;
+    uint32_t fast_levels;   // bit l: level l is hashed and its size is a power of two
 };
 
 template <int CD>
@@ -129,8 +131,26 @@ __device__ __forceinline__ void field_mask_pack(const f4v (&gacc)[4], const s8v 
 //      (SCQ_PACE): atomics are fire-and-forget, but a burst of ~45 back-to-back wave-instructions
 //      blocks at issue once the memory side is saturated, and with one wave per SIMD a blocked
 //      wave is an idle SIMD.  Pacing lets the atomic service time hide under the MFMA/VALU work.
+#ifdef NSR_ABL_STATS
+__device__ unsigned long long g_stats[8];
+#define NSR_STAT_ALWAYS(i, n) do { if (lane == 0) atomicAdd(&g_stats[i], (unsigned long long)(n)); } while (0)
+#ifdef NSR_ABL_COUNTS
+#define NSR_STAT(i, n) NSR_STAT_ALWAYS(i, n)
+#else
+#define NSR_STAT(i, n) do { } while (0)
+#endif
+#else
+#define NSR_STAT(i, n) do { } while (0)
+#endif
+#ifdef NSR_ABL_PRIV_ROWS
+#ifndef NSR_ABL_PRIV_COPIES
+#define NSR_ABL_PRIV_COPIES 8
+#endif
+__device__ float g_priv[NSR_ABL_PRIV_COPIES][(NSR_ABL_PRIV_ROWS + 8) * 4];
+#endif
 constexpr int SCQ_CAP = 1024;    // records per wave (power of two)
 constexpr int SCQ_MASK = SCQ_CAP - 1;
+constexpr int SCATTER_PACE = 0;  // atomic wave-instructions per corner pair in the last two scatter calls (measured: 2 is slower than 0)
 constexpr int SCQ_SEEN = 512;    // direct-mapped "row -> record still in the ring" table per wave
 struct ScatterQueue {
     uint32_t *rows;              // [SCQ_CAP]
@@ -140,112 +160,203 @@ struct ScatterQueue {
     int head, tail;              // wave-uniform, monotonically increasing record indices
 };
 
+// DPP row shifts with bound_ctrl:1 -- lanes shifted in from outside the 16-lane row read 0, so no
+// "old" register has to be initialised and the move can fold into the consuming VOP2
 template <int K>
-__device__ __forceinline__ float dpp_shr_f(float v, float fill) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, fill), __builtin_bit_cast(int, v),
-                                                                 0x110 + K, 0xF, 0xF, false));
+__device__ __forceinline__ float dpp_shr_f(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x110 + K, 0xF, 0xF, true));
 }
-template <int K>
-__device__ __forceinline__ uint32_t dpp_shr_u(uint32_t v, uint32_t fill) {
-    return (uint32_t)__builtin_amdgcn_update_dpp((int)fill, (int)v, 0x110 + K, 0xF, 0xF, false);
+__device__ __forceinline__ uint32_t dpp_shr1_u(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true);
 }
-__device__ __forceinline__ uint32_t dpp_shl1_u(uint32_t v, uint32_t fill) {
-    return (uint32_t)__builtin_amdgcn_update_dpp((int)fill, (int)v, 0x101, 0xF, 0xF, false);
+__device__ __forceinline__ uint32_t dpp_shl1_u(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x101, 0xF, 0xF, true);
 }
 
-// one Hillis-Steele step of a segmented inclusive scan over a 16-lane DPP row
+// one Hillis-Steele step of a segmented inclusive scan over a 16-lane DPP row.  m is 1.0 while the
+// lanes K to the left still belong to this lane's run, 0.0 once a run head lies in between; the zero
+// shifted in from outside the row ends every run at the row boundary.
 template <int K>
-__device__ __forceinline__ void seg_step(float4 &v, uint32_t &f) {
-    const float a = dpp_shr_f<K>(v.x, 0.f), b = dpp_shr_f<K>(v.y, 0.f), c = dpp_shr_f<K>(v.z, 0.f), d = dpp_shr_f<K>(v.w, 0.f);
-    const uint32_t fu = dpp_shr_u<K>(f, 1u);      // lanes shifted in from outside the row count as heads
-    const float m = f ? 0.0f : 1.0f;              // branchless: a 4-add body is cheaper than an exec-mask branch
+__device__ __forceinline__ void seg_step(float4 &v, float &m) {
+    const float a = dpp_shr_f<K>(v.x), b = dpp_shr_f<K>(v.y), c = dpp_shr_f<K>(v.z), d = dpp_shr_f<K>(v.w);
+    const float mu = dpp_shr_f<K>(m);
     v.x = fmaf(a, m, v.x); v.y = fmaf(b, m, v.y); v.z = fmaf(c, m, v.z); v.w = fmaf(d, m, v.w);
-    f |= fu;
+    m *= mu;
 }
 
-// Issues up to `max_instr` wave-instructions of 16 records (4 lanes per record: the 4 dwords of an
-// interleaved row leave as ONE 16-byte request).  Only full groups unless `flush`.
-__device__ __forceinline__ void scq_pace(ScatterQueue &q, float *__restrict__ gt, int lane, bool td, bool tc, int max_instr,
+// N full groups of 16 records: all LDS reads first, then the N atomic wave-instructions (4 lanes per
+// record: the 4 dwords of an interleaved row leave as ONE 16-byte request).  With one wave per SIMD an
+// LDS round trip per instruction would be fully exposed.  Ring rows are stored +1 (see the scatter):
+// gt1 = grad_tables - 4 floats.
+template <int N>
+__device__ __forceinline__ void scq_drain(ScatterQueue &q, float *__restrict__ gt1, int t, int i, bool on) {
+    uint32_t row[N];
+    float v[N];
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+        const int slot = (q.head + 16 * k + t) & SCQ_MASK;
+        row[k] = q.rows[slot];
+        v[k] = reinterpret_cast<const float *>(q.vals)[slot * 4 + i];
+    }
+    if (on) {
+#pragma unroll
+        for (int k = 0; k < N; k++) {
+#ifdef NSR_ABL_PRIV_ROWS
+            if (row[k] <= NSR_ABL_PRIV_ROWS) atomicAdd(&g_priv[blockIdx.x % NSR_ABL_PRIV_COPIES][row[k] * 4 + i], v[k]);
+            else atomicAdd(gt1 + (size_t)row[k] * 4 + i, v[k]);
+#elif !defined(NSR_ABL_NO_ATOMIC)
+            atomicAdd(gt1 + (size_t)row[k] * 4 + i, v[k]);
+#else
+            if (row[k] == 0xFFFFFFFFu) gt1[i] = v[k];
+#endif
+        }
+    }
+    q.head += 16 * N;
+}
+
+// Issues up to `max_instr` atomic wave-instructions of 16 records.  Only full groups unless `flush`.
+__device__ __forceinline__ void scq_pace(ScatterQueue &q, float *__restrict__ gt1, int lane, bool td, bool tc, int max_instr,
                                          bool flush) {
     __builtin_amdgcn_wave_barrier();
     const int t = lane >> 2, i = lane & 3;
     const bool on = (i < 2) ? td : tc;
-    for (int k = 0; k < max_instr; k++) {
-        const int avail = q.tail - q.head;
-        if (avail <= 0 || (avail < 16 && !flush)) break;
-        const int n = avail < 16 ? avail : 16;
+    int full = (q.tail - q.head) >> 4;
+    if (full > max_instr) full = max_instr;
+    NSR_STAT(2, full);
+    for (; full >= 4; full -= 4) scq_drain<4>(q, gt1, t, i, on);
+    if (full >= 2) { scq_drain<2>(q, gt1, t, i, on); full -= 2; }
+    if (full >= 1) scq_drain<1>(q, gt1, t, i, on);
+    if (flush) {
+        const int n = q.tail - q.head;          // < 16 when max_instr did not bound the loop above
         if (t < n && on) {
             const int slot = (q.head + t) & SCQ_MASK;
-            const uint32_t row = q.rows[slot];
-            const float v = reinterpret_cast<const float *>(q.vals)[slot * 4 + i];
-            atomicAdd(gt + (size_t)row * 4 + i, v);
+            atomicAdd(gt1 + (size_t)q.rows[slot] * 4 + i, reinterpret_cast<const float *>(q.vals)[slot * 4 + i]);
         }
-        q.head += n;
+        q.head += n < 16 ? n : 16;
     }
     __builtin_amdgcn_wave_barrier();
 }
 
 // One level, all 8 corners, for the 16-sample tile (this lane = one sample of one level group).
-__device__ __forceinline__ void field_scatter_level(const NsrLevel &lv, ScatterQueue &q, float *__restrict__ gt, float u0, float u1,
-                                                    float u2, bool live, float gd0, float gd1, float gc0, float gc1, int lane,
-                                                    bool td, bool tc) {
-    float f[3] = {0.f, 0.f, 0.f};
-    uint32_t c[3] = {0u, 0u, 0u};
-    if (live) {
-        nsr_grid_locate(u0, lv.resolution, 1, f[0], c[0]);
-        nsr_grid_locate(u1, lv.resolution, 1, f[1], c[1]);
-        nsr_grid_locate(u2, lv.resolution, 1, f[2], c[2]);
-    }
+// FAST: every level handled by this call (one per 16-lane group) is hashed with a power-of-two size
+// (wave-uniform, from the host's level table), so the row is (x ^ y*P1 ^ z*P2) & (size-1): the same
+// value nsr_grid_row computes, without the per-lane dense/hash select and the invariant-divisor modulo.
+// Dead lanes arrive with u = 0 and zero gradients: they map to cell 0 with an all-zero value, extend a
+// neighbour's run harmlessly or form a zero run that is never pushed.
+template <bool FAST, int PACE>
+__device__ __forceinline__ void field_scatter_level(const NsrLevel &lv, ScatterQueue &q, float *__restrict__ gt1, float u0, float u1,
+                                                    float u2, float gd0, float gd1, float gc0, float gc1, bool swapx,
+                                                    int lane, bool td, bool tc) {
+#ifdef NSR_ABL_NO_SCATTER
+    if (lv.resolution != 0xFFFFFFFFu) return;
+#endif
+    float f[3];
+    uint32_t c[3];
+    nsr_grid_locate(u0, lv.resolution, 1, f[0], c[0]);
+    nsr_grid_locate(u1, lv.resolution, 1, f[1], c[1]);
+    nsr_grid_locate(u2, lv.resolution, 1, f[2], c[2]);
+    // (wx*wy)*wz, the product order of the forward interpolation
+    const float wxy[4] = {(1 - f[0]) * (1 - f[1]), f[0] * (1 - f[1]), (1 - f[0]) * f[1], f[0] * f[1]};
+    const float wz[2] = {1 - f[2], f[2]};
+    const uint32_t hy[2] = {c[1] * 2654435761u, (c[1] + 1) * 2654435761u};
+    const uint32_t hz[2] = {c[2] * 805459861u, (c[2] + 1) * 805459861u};
+    const uint32_t off1 = lv.offset + 1u, msk = lv.size - 1u;
+    // stream 0 = the TRAILING x corner with respect to the ray's direction of travel, stream 1 = the leading
+    // one: when the ray steps one cell in x, lane s+1's trailing corner is lane s's leading corner
+    const uint32_t cx[2] = {c[0] + (swapx ? 1u : 0u), c[0] + (swapx ? 0u : 1u)};
+    const float wsel[2][2] = {{swapx ? wxy[1] : wxy[0], swapx ? wxy[3] : wxy[2]}, {swapx ? wxy[0] : wxy[1], swapx ? wxy[2] : wxy[3]}};
+    // make room for this call's records (rare: the paced drain keeps the ring nearly empty)
+    if (q.tail - q.head > SCQ_CAP - 512) { NSR_STAT(3, 1); scq_pace(q, gt1, lane, td, tc, 32, false); }
+    // Corners are handled as x / x+1 PAIRS and a lane's two records are adjacent in the ring: the hash
+    // prime for x is 1, so the two rows are neighbours (same 64-byte line 3 times out of 4) and leave in
+    // the same 16-record atomic instruction, where the memory side merges them into one request
+    // (tools/scatter_sim.py: 26.1 -> 19.1 requests per sample on the bench scene).
 #pragma unroll
-    for (uint32_t idx = 0; idx < 8; idx++) {
-        float w = 1;
-        uint32_t p[3];
+    for (uint32_t pr = 0; pr < 4; pr++) {
+        uint32_t key[2], hsh[2], seen_r[2];
+        int seen_j[2];
+        float4 v[2];
+        float m[2];
+        bool push[2];
 #pragma unroll
-        for (uint32_t d = 0; d < 3; d++) {
-            if ((idx & (1u << d)) == 0) { w *= 1 - f[d]; p[d] = c[d]; }
-            else { w *= f[d]; p[d] = c[d] + 1; }
+        for (uint32_t x = 0; x < 2; x++) {
+            // run = consecutive samples with the same table row.  Keys are row + 1, so the zero a DPP shift
+            // reads outside the row never matches; the drain subtracts the 1 through its base pointer.
+            if (FAST) key[x] = off1 + ((cx[x] ^ hy[pr & 1] ^ hz[pr >> 1]) & msk);
+            else key[x] = off1 + nsr_grid_row(lv, cx[x], c[1] + (pr & 1), c[2] + (pr >> 1), 0u);
+            // dedupe-table lookup issued NOW (it only needs the key) so that the DPP scan below hides the
+            // LDS latency.  x-neighbouring rows differ in their low bits: they never evict each other.
+            hsh[x] = key[x] & (SCQ_SEEN - 1);
+            seen_r[x] = q.seen_row[hsh[x]];
+            seen_j[x] = q.seen_idx[hsh[x]];
+            const float w = wsel[x][pr & 1] * wz[pr >> 1];
+            v[x] = make_float4(w * gd0, w * gd1, w * gc0, w * gc1);
+            m[x] = (dpp_shr1_u(key[x]) != key[x]) ? 0.0f : 1.0f;
+            push[x] = dpp_shl1_u(key[x]) != key[x];           // run tail
         }
-        // run = consecutive samples with the same table row; dead lanes get unique keys so they
-        // never merge with anything and never emit
-        const uint32_t key = live ? lv.offset + nsr_grid_row(lv, p[0], p[1], p[2], 0u) : (0xFFFFFF00u | (uint32_t)lane);
-        float4 v = live ? make_float4(w * gd0, w * gd1, w * gc0, w * gc1) : make_float4(0.f, 0.f, 0.f, 0.f);
-        uint32_t head = (dpp_shr_u<1>(key, 0xFFFFFFFFu) != key) ? 1u : 0u;
-        const bool tail = dpp_shl1_u(key, 0xFFFFFFFFu) != key;
-        seg_step<1>(v, head);
-        seg_step<2>(v, head);
-        seg_step<4>(v, head);
-        seg_step<8>(v, head);
-        // a run whose summed gradient is exactly zero (e.g. samples behind an opaque surface: the
-        // composite backward gives them zero gradient) adds nothing: skip its request
-        bool push = tail && live && (v.x != 0.f || v.y != 0.f || v.z != 0.f || v.w != 0.f);
-        // make room first (rare: the paced drain keeps the ring nearly empty)
-        if (q.tail - q.head > SCQ_CAP - 64) scq_pace(q, gt, lane, td, tc, 8, false);
-        // Exact duplicate addresses are the one thing the atomic path never merges (tools/
-        // atomic_merge_rule.hip), and they are common: face-adjacent cells share 4 of their 8 corner rows,
-        // runs continue across tiles.  If this row was pushed recently and its record is still in the
-        // ring, add into that record instead of emitting another request.
-        const uint32_t hsh = (key * 2654435761u) >> (32 - 9);
-        if (push) {
-            const uint32_t r = q.seen_row[hsh];
-            const int j = q.seen_idx[hsh];
-            if (r == key && (uint32_t)(j - q.head) < (uint32_t)(q.tail - q.head)) {
-                float *dst = reinterpret_cast<float *>(q.vals + (j & SCQ_MASK));
-                atomicAdd(dst + 0, v.x); atomicAdd(dst + 1, v.y); atomicAdd(dst + 2, v.z); atomicAdd(dst + 3, v.w);
-                push = false;
+        // leading stream first; where the next lane's trailing row is this lane's leading row (the ray
+        // stepped one cell in x) the finished run sum moves over in registers and continues there, instead
+        // of becoming a second record with the same address in the same atomic instruction
+        const bool absorb = dpp_shr1_u(key[1]) == key[0];      // my trailing run continues lane s-1's leading run
+        const bool absorbed = dpp_shl1_u(key[0]) == key[1];    // my leading run is continued by lane s+1
+#ifndef NSR_ABL_NO_SCAN
+        seg_step<1>(v[1], m[1]); seg_step<2>(v[1], m[1]); seg_step<4>(v[1], m[1]); seg_step<8>(v[1], m[1]);
+        {
+            const float a = dpp_shr_f<1>(v[1].x), b2 = dpp_shr_f<1>(v[1].y), c2 = dpp_shr_f<1>(v[1].z), d = dpp_shr_f<1>(v[1].w);
+            const float t = absorb ? 1.0f : 0.0f;
+            v[0].x = fmaf(a, t, v[0].x); v[0].y = fmaf(b2, t, v[0].y); v[0].z = fmaf(c2, t, v[0].z); v[0].w = fmaf(d, t, v[0].w);
+        }
+        seg_step<1>(v[0], m[0]); seg_step<2>(v[0], m[0]); seg_step<4>(v[0], m[0]); seg_step<8>(v[0], m[0]);
+#endif
+        push[1] = push[1] && !absorbed;
+#pragma unroll
+        for (uint32_t x = 0; x < 2; x++) {
+            // a run whose summed gradient is exactly zero (e.g. samples behind an opaque surface: the
+            // composite backward gives them zero gradient) adds nothing: skip its request
+            const uint32_t any = __float_as_uint(v[x].x) | __float_as_uint(v[x].y) | __float_as_uint(v[x].z) | __float_as_uint(v[x].w);
+            push[x] = push[x] && (any << 1) != 0u;
+#ifdef NSR_ABL_NO_PUSH
+            push[x] = push[x] && m[x] == 12345.f;
+#endif
+#ifdef NSR_ABL_MIN_ROW
+            push[x] = push[x] && key[x] > NSR_ABL_MIN_ROW;
+#endif
+#ifdef NSR_ABL_MAX_ROW
+            push[x] = push[x] && key[x] <= NSR_ABL_MAX_ROW;
+#endif
+#ifndef NSR_ABL_NO_DEDUPE
+            // Exact duplicate addresses are the one thing the atomic path never merges (tools/
+            // atomic_merge_rule.hip), and they are common: face-adjacent cells share 4 of their 8 corner
+            // rows, runs continue across tiles.  If this row was pushed recently and its record is still in
+            // the ring, add into that record instead of emitting another request.
+            if (push[x] && seen_r[x] == key[x] && (uint32_t)(seen_j[x] - q.head) < (uint32_t)(q.tail - q.head)) {
+                float *dst = reinterpret_cast<float *>(q.vals + (seen_j[x] & SCQ_MASK));
+                atomicAdd(dst + 0, v[x].x); atomicAdd(dst + 1, v[x].y); atomicAdd(dst + 2, v[x].z); atomicAdd(dst + 3, v[x].w);
+                push[x] = false;
             }
+#endif
         }
-        const unsigned long long mask = __ballot(push);
-        // records of one corner stay contiguous in the ring: consecutive samples of a ray step
-        // through x-neighbouring rows (the hash prime for x is 1), which the drain coalesces per line
-        if (push) {
-            const int idxr = q.tail + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-            const int slot = idxr & SCQ_MASK;
-            q.rows[slot] = key;
-            q.vals[slot] = v;
-            q.seen_row[hsh] = key;
-            q.seen_idx[hsh] = idxr;
+        const unsigned long long mask0 = __ballot(push[0]), mask1 = __ballot(push[1]);
+        const int below = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask0, 0u)) +
+                          (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask1, 0u));
+        const int idx0 = q.tail + below, idx1 = idx0 + (push[0] ? 1 : 0);
+        if (push[0]) {
+            const int slot = idx0 & SCQ_MASK;
+            q.rows[slot] = key[0];
+            q.vals[slot] = v[0];
+            q.seen_row[hsh[0]] = key[0];
+            q.seen_idx[hsh[0]] = idx0;
         }
-        q.tail += (int)__popcll(mask);
+        if (push[1]) {
+            const int slot = idx1 & SCQ_MASK;
+            q.rows[slot] = key[1];
+            q.vals[slot] = v[1];
+            q.seen_row[hsh[1]] = key[1];
+            q.seen_idx[hsh[1]] = idx1;
+        }
+        q.tail += (int)__popcll(mask0) + (int)__popcll(mask1);
+        NSR_STAT(0, __popcll(mask0) + __popcll(mask1));
+        if (PACE > 0) scq_pace(q, gt1, lane, td, tc, PACE, false);
     }
 }
 
@@ -286,6 +397,7 @@ k_field_bwd(FieldBwdArgs b) {
         q.head = q.tail = 0;
     }
     const bool td = b.train_density != 0, tc = b.train_color != 0;
+    float *const gt1 = b.grad_tables - 4;      // ring rows are stored +1 (field_scatter_level)
     // weight-gradient accumulators (60 tiles x 4 regs), resident for the whole launch
     f4v w_r3[4], w_r2[16], w_r1[4], w_c1b[4], w_c1a[8], w_k2[4], w_k1[8], w_d2[4], w_d1[8];
     {
@@ -303,53 +415,36 @@ k_field_bwd(FieldBwdArgs b) {
     // atomics are issued by pace points inside the NEXT tile's dgrad / wgrad section, where no load
     // result is consumed.  In the straightforward order every load-use waits for a full trip of
     // freshly issued atomics to the memory-side atomic unit (41 % of the wave's cycles, SQ_WAIT_ANY).
+    // A tile's raw inputs: loads only, nothing here consumes a loaded value (a use would make the
+    // compiler wait for the whole memory round trip inside the prefetch).  Lanes past the sample count
+    // read sample 0 (always in bounds) and are masked where the values are used.
     struct TileIn {
-        uint32_t m;
-        bool valid, live;
-        float u0, u1, u2;
+        float x0, x1, x2;
         s8v xd, xc;
         float gsig;        // grad_sigmas[m] (used by the g == 0 lanes)
         float grgb[4];     // grad_rgbs[m, 4g .. 4g+3]
     };
     auto load_tile = [&](uint32_t tile) {
         TileIn r;
-        r.m = tile * 16 + s;
-        r.valid = r.m < Mc;
-        r.u0 = r.u1 = r.u2 = 0.f;
-        if (r.valid) {
-            r.u0 = field_unit(a.xyzs[(size_t)r.m * 3 + 0], a.bmin[0], a.bsize[0]);
-            r.u1 = field_unit(a.xyzs[(size_t)r.m * 3 + 1], a.bmin[1], a.bsize[1]);
-            r.u2 = field_unit(a.xyzs[(size_t)r.m * 3 + 2], a.bmin[2], a.bsize[2]);
-        }
-        r.live = r.valid && !(r.u0 < 0 || r.u0 > 1 || r.u1 < 0 || r.u1 > 1 || r.u2 < 0 || r.u2 > 1);
-        // every global load of the tile is issued HERE, in one group, after the atomic-free scatter
-        // phase of the previous tile: a load placed after a pace point would wait (vmcnt retires in
-        // order, and the compiler can only use vmcnt(0) around the dynamic pace loops) for atomics
-        // issued a few cycles earlier, i.e. for a full trip to the memory-side atomic unit
-        r.gsig = 0.f;
+        const uint32_t m = tile * 16 + s;
+        const size_t mc = m < Mc ? m : 0u;
+        r.x0 = a.xyzs[mc * 3 + 0];
+        r.x1 = a.xyzs[mc * 3 + 1];
+        r.x2 = a.xyzs[mc * 3 + 2];
+        r.gsig = b.grad_sigmas[mc];
+        const float *gp = b.grad_rgbs + mc * a.C_ch;
+        if (a.C_ch == 8) {
+            const float4 t4 = reinterpret_cast<const float4 *>(gp)[g & 1];
+            r.grgb[0] = t4.x; r.grgb[1] = t4.y; r.grgb[2] = t4.z; r.grgb[3] = t4.w;
+        } else {
 #pragma unroll
-        for (int e = 0; e < 4; e++) r.grgb[e] = 0.f;
-        if (r.valid) {
-            r.gsig = b.grad_sigmas[r.m];
-            const float *gp = b.grad_rgbs + (size_t)r.m * a.C_ch;
-            if (a.C_ch == 8) {
-                if (g < 2) {
-                    const float4 t4 = reinterpret_cast<const float4 *>(gp)[g];
-                    r.grgb[0] = t4.x; r.grgb[1] = t4.y; r.grgb[2] = t4.z; r.grgb[3] = t4.w;
-                }
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; e++)
-                    if ((uint32_t)(4 * g + e) < a.C_ch) r.grgb[e] = gp[4 * g + e];
-            }
+            for (int e = 0; e < 4; e++) r.grgb[e] = gp[(uint32_t)(4 * g + e) < a.C_ch ? 4 * g + e : 0];
         }
         if (a.feats) {
             // the forward saved this lane's two B fragments: two 16-byte loads instead of 32 gathers
             const s8v *fi = reinterpret_cast<const s8v *>(a.feats) + ((size_t)tile * 64 + lane) * 2;
             r.xd = fi[0];
             r.xc = fi[1];
-        } else {
-            field_encode<TT, CD, false>(lds_lv, tables, r.u0, r.u1, r.u2, r.live, g, r.xd, r.xc);
         }
         return r;
     };
@@ -357,15 +452,37 @@ k_field_bwd(FieldBwdArgs b) {
     TileIn cur;
     if (t_begin + wave < t_end) cur = load_tile(t_begin + wave);
 
+#ifdef NSR_ABL_STATS
+    unsigned long long tacc[4] = {0, 0, 0, 0};
+#define NSR_TICK(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#define NSR_TACC(i, a, c) tacc[i] += (c) - (a)
+#else
+#define NSR_TICK(var) do { } while (0)
+#define NSR_TACC(i, a, c) do { } while (0)
+#endif
     for (uint32_t tile = t_begin + wave; tile < t_end; tile += tstep) {
-        const uint32_t m = cur.m;
-        const bool valid = cur.valid, live = cur.live;
-        const float u0 = cur.u0, u1 = cur.u1, u2 = cur.u2;
-        const float cur_gsig = cur.gsig;
-        const float cur_grgb[4] = {cur.grgb[0], cur.grgb[1], cur.grgb[2], cur.grgb[3]};
+        NSR_TICK(tk0);
+#ifdef NSR_ABL_STATS
+        __builtin_amdgcn_s_waitcnt(0);
+#endif
+        NSR_TICK(tk1);
+        NSR_TACC(0, tk0, tk1);
+        const uint32_t m = tile * 16 + s;
+        const bool valid = m < Mc;
+        const float u0 = valid ? field_unit(cur.x0, a.bmin[0], a.bsize[0]) : 0.f;
+        const float u1 = valid ? field_unit(cur.x1, a.bmin[1], a.bsize[1]) : 0.f;
+        const float u2 = valid ? field_unit(cur.x2, a.bmin[2], a.bsize[2]) : 0.f;
+        const bool live = valid && !(u0 < 0 || u0 > 1 || u1 < 0 || u1 > 1 || u2 < 0 || u2 > 1);
+        const float cur_gsig = valid ? cur.gsig : 0.f;
+        float cur_grgb[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++)
+            cur_grgb[e] = (valid && (a.C_ch == 8 ? g < 2 : (uint32_t)(4 * g + e) < a.C_ch)) ? cur.grgb[e] : 0.f;
+        // no saved features: gather them now (dependent loads, the slow path)
+        if (!a.feats) field_encode<TT, CD, false>(lds_lv, tables, u0, u1, u2, live, g, cur.xd, cur.xc);
 
         // paced drain of the previous tile's records: SCQ_PACE(n) issues <= n atomic wave-instructions
-#define SCQ_PACE(n) scq_pace(q, b.grad_tables, lane, td, tc, (n), false)
+#define SCQ_PACE(n) scq_pace(q, gt1, lane, td, tc, (n), false)
         // ================= recompute forward, keeping rounded activations ====================
         s8v xd[1] = {cur.xd}, xc[1] = {cur.xc};
         f4v h[4];
@@ -499,22 +616,68 @@ k_field_bwd(FieldBwdArgs b) {
         // as the forward encode.
         // this tile's scatter: VALU + LDS only (records go to the ring; atomics are issued by the pace
         // points of the NEXT tile's dgrad / wgrad section), then the next tile's loads
+        NSR_TICK(tk2);
+        NSR_TACC(1, tk1, tk2);
+        // Next tile's loads go out BEFORE this tile's scatter: the scatter touches LDS only (its records are
+        // turned into atomics by the pace points of the next tile), so by the next loop top both these loads
+        // and the atomics issued ahead of them (vmcnt retires in order) have had the whole scatter to land.
+        TileIn nxt = cur;
+        if (tile + tstep < t_end) nxt = load_tile(tile + tstep);
+        NSR_TICK(tk3);
+        NSR_TACC(3, tk2, tk3);
         if (td || tc) {
             const int lvl[4] = {2 * g, 2 * g + 1, 8 + 2 * g, 9 + 2 * g};
+            // x direction of travel of this lane's ray, from its neighbour sample (any value is correct,
+            // a consistent one lets field_scatter_level chain the runs of x-adjacent cells)
+            const bool swapx = (s == 15 ? u0 - dpp_shr_f<1>(u0) : __builtin_bit_cast(float, dpp_shl1_u(__builtin_bit_cast(uint32_t, u0))) - u0) < 0.f;
+            // levels per call (one per lane group): {0,2,4,6} {1,3,5,7} {8,10,12,14} {9,11,13,15}
+            const uint32_t call_levels[4] = {0x0055u, 0x00AAu, 0x5500u, 0xAA00u};
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 const NsrLevel lv = lds_lv[lvl[i]];
                 const int t = i >> 1, e0 = 2 * (i & 1);
-                field_scatter_level(lv, q, b.grad_tables, u0, u1, u2, live, gxd[t][e0], gxd[t][e0 + 1], gxc[t][e0], gxc[t][e0 + 1],
-                                    lane, td, tc);
+                // dead lanes carry zero gradients (see field_scatter_level)
+                const float s0 = live ? gxd[t][e0] : 0.f, s1 = live ? gxd[t][e0 + 1] : 0.f;
+                const float s2 = live ? gxc[t][e0] : 0.f, s3 = live ? gxc[t][e0 + 1] : 0.f;
+#ifdef NSR_ABL_NO_MLP
+#define s0 (live ? cur_gsig + 1.f : 0.f)
+#define s1 (live ? cur_gsig + 2.f : 0.f)
+#define s2 (live ? cur_grgb[0] + 1.f : 0.f)
+#define s3 (live ? cur_grgb[1] + 2.f : 0.f)
+#endif
+                // The first two calls issue no atomics: the prefetch above and the atomics of the dgrad /
+                // wgrad pace points land meanwhile.  Then the prefetched registers are touched -- the one
+                // place the compiler has to wait for memory (vmcnt(0): gfx9 counts loads and atomics in one
+                // counter and may not assume an order between them) -- and the last two calls pace atomics
+                // again, which stay in flight across the loop back-edge.
+                if (i == 2)
+                    asm volatile("" ::"v"(nxt.x0), "v"(nxt.x1), "v"(nxt.x2), "v"(nxt.gsig), "v"(nxt.grgb[0]), "v"(nxt.grgb[1]),
+                                 "v"(nxt.grgb[2]), "v"(nxt.grgb[3]), "v"(nxt.xd), "v"(nxt.xc));
+                const bool fast = (b.fast_levels & call_levels[i]) == call_levels[i];
+                if (i < 2) {
+                    if (fast) field_scatter_level<true, 0>(lv, q, gt1, u0, u1, u2, s0, s1, s2, s3, swapx, lane, td, tc);
+                    else field_scatter_level<false, 0>(lv, q, gt1, u0, u1, u2, s0, s1, s2, s3, swapx, lane, td, tc);
+                } else {
+                    if (fast) field_scatter_level<true, SCATTER_PACE>(lv, q, gt1, u0, u1, u2, s0, s1, s2, s3, swapx, lane, td, tc);
+                    else field_scatter_level<false, SCATTER_PACE>(lv, q, gt1, u0, u1, u2, s0, s1, s2, s3, swapx, lane, td, tc);
+                }
             }
         }
-        if (tile + tstep < t_end) cur = load_tile(tile + tstep);
+        NSR_TICK(tk4);
+        NSR_TACC(2, tk3, tk4);
+        cur = nxt;
     }
-    if (td || tc) scq_pace(q, b.grad_tables, lane, td, tc, 1 << 20, true);
+#ifdef NSR_ABL_STATS
+    for (int i = 0; i < 4; i++) NSR_STAT_ALWAYS(4 + i, tacc[i]);
+#endif
+    if (td || tc) scq_pace(q, gt1, lane, td, tc, 1 << 20, true);
 
     // ---- flush this wave's weight gradients -------------------------------------------------------
+#ifdef NSR_ABL_NO_MLP
+    if (false) {
+#else
     if (b.grad_mlp) {
+#endif
         float *gm = b.grad_mlp;
         field_wgrad_flush<1, 4>(gm + P_R3, 64, 0, 3, w_r3, lane);
         field_wgrad_flush<4, 4>(gm + P_R2, 64, 0, 64, w_r2, lane);
@@ -554,14 +717,32 @@ int nsr_field_backward(const nsr_field_desc *desc, const void *tables, const flo
     if (feats && ((uintptr_t)feats & 15u)) return NSR_ERR_INVALID_ARG;
     b.grad_sigmas = grad_sigmas; b.grad_rgbs = grad_rgbs; b.grad_tables = grad_tables; b.grad_mlp = grad_mlp;
     b.train_density = train_density_table; b.train_color = train_color_table; b.nc = desc->num_classes;
+    b.fast_levels = 0;
+    for (uint32_t l = 0; l < desc->L; l++) {
+        const NsrLevel &v = b.f.lv[l];
+        if (v.use_hash && v.size && (v.size & (v.size - 1)) == 0) b.fast_levels |= 1u << l;
+    }
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid(nblocks), block(BWD_THREADS);
+#ifdef NSR_ABL_STATS
+#define NSR_ABL_REPORT()                                                                                          \
+    do {                                                                                                          \
+        unsigned long long h[8], z[8] = {0};                                                                      \
+        hipDeviceSynchronize();                                                                                   \
+        hipMemcpyFromSymbol(h, HIP_SYMBOL(g_stats), sizeof(h));                                                   \
+        hipMemcpyToSymbol(HIP_SYMBOL(g_stats), z, sizeof(z));                                                     \
+        fprintf(stderr, "[abl] M=%u records=%llu hits=%llu drain_instr=%llu forced=%llu clk wait=%llu mlp=%llu scatter=%llu loads=%llu\n", M, h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]); \
+    } while (0)
+#else
+#define NSR_ABL_REPORT() do { } while (0)
+#endif
 #define NSR_BWD_LAUNCH(TT, CD)                                                                                \
     do {                                                                                                       \
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_field_bwd<TT, CD>),                          \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)BWD_LDS_BYTES) != hipSuccess) \
             return NSR_ERR_LAUNCH;                                                                             \
         hipLaunchKernelGGL((k_field_bwd<TT, CD>), grid, block, BWD_LDS_BYTES, s, b);                           \
+        NSR_ABL_REPORT();                                                                                      \
         return nsr_launch_status();                                                                            \
     } while (0)
     if (desc->table_dtype == NSR_F32 && desc->compute_dtype == NSR_F16) NSR_BWD_LAUNCH(float, NSR_F16);
