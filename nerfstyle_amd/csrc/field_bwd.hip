@@ -150,13 +150,17 @@ __device__ float g_priv[NSR_ABL_PRIV_COPIES][(NSR_ABL_PRIV_ROWS + 8) * 4];
 #endif
 constexpr int SCQ_CAP = 1024;    // records per wave (power of two)
 constexpr int SCQ_MASK = SCQ_CAP - 1;
+#ifndef NSR_SCQ_KEEP
+#define NSR_SCQ_KEEP 512
+#endif
+constexpr int SCQ_KEEP = NSR_SCQ_KEEP;     // records the paced drain leaves in the ring for cross-tile merging
 constexpr int SCATTER_PACE = 0;  // atomic wave-instructions per corner pair in the last two scatter calls (measured: 2 is slower than 0)
-constexpr int SCQ_SEEN = 512;    // direct-mapped "row -> record still in the ring" table per wave
+constexpr int SCQ_SEEN = 1024;   // direct-mapped "row -> record still in the ring" table per wave (record index only:
+                                 // the row is verified against the ring itself)
 struct ScatterQueue {
     uint32_t *rows;              // [SCQ_CAP]
     float4 *vals;                // [SCQ_CAP]
-    uint32_t *seen_row;          // [SCQ_SEEN] last row pushed under this hash
-    int *seen_idx;               // [SCQ_SEEN] its (monotonic) record index
+    int *seen_idx;               // [SCQ_SEEN] (monotonic) index of the last record pushed under this hash
     int head, tail;              // wave-uniform, monotonically increasing record indices
 };
 
@@ -216,11 +220,13 @@ __device__ __forceinline__ void scq_drain(ScatterQueue &q, float *__restrict__ g
 
 // Issues up to `max_instr` atomic wave-instructions of 16 records.  Only full groups unless `flush`.
 __device__ __forceinline__ void scq_pace(ScatterQueue &q, float *__restrict__ gt1, int lane, bool td, bool tc, int max_instr,
-                                         bool flush) {
+                                         bool flush, int keep = 0) {
     __builtin_amdgcn_wave_barrier();
     const int t = lane >> 2, i = lane & 3;
     const bool on = (i < 2) ? td : tc;
-    int full = (q.tail - q.head) >> 4;
+    // `keep` newest records stay in the ring (paced drains only): the next tile's scatter can still merge
+    // into them through the dedupe table
+    int full = (q.tail - q.head - keep) >> 4;
     if (full > max_instr) full = max_instr;
     NSR_STAT(2, full);
     for (; full >= 4; full -= 4) scq_drain<4>(q, gt1, t, i, on);
@@ -265,14 +271,14 @@ __device__ __forceinline__ void field_scatter_level(const NsrLevel &lv, ScatterQ
     // one: when the ray steps one cell in x, lane s+1's trailing corner is lane s's leading corner
     const uint32_t cx[2] = {c[0] + (swapx ? 1u : 0u), c[0] + (swapx ? 0u : 1u)};
     const float wsel[2][2] = {{swapx ? wxy[1] : wxy[0], swapx ? wxy[3] : wxy[2]}, {swapx ? wxy[0] : wxy[1], swapx ? wxy[2] : wxy[3]}};
-    // make room for this call's records (rare: the paced drain keeps the ring nearly empty)
-    if (q.tail - q.head > SCQ_CAP - 512) { NSR_STAT(3, 1); scq_pace(q, gt1, lane, td, tc, 32, false); }
     // Corners are handled as x / x+1 PAIRS and a lane's two records are adjacent in the ring: the hash
     // prime for x is 1, so the two rows are neighbours (same 64-byte line 3 times out of 4) and leave in
     // the same 16-record atomic instruction, where the memory side merges them into one request
     // (tools/scatter_sim.py: 26.1 -> 19.1 requests per sample on the bench scene).
 #pragma unroll
     for (uint32_t pr = 0; pr < 4; pr++) {
+        // make room for this pair's (at most 128) records; rare
+        if (q.tail - q.head > SCQ_CAP - 128) { NSR_STAT(3, 1); scq_pace(q, gt1, lane, td, tc, 16, false); }
         uint32_t key[2], hsh[2], seen_r[2];
         int seen_j[2];
         float4 v[2];
@@ -287,8 +293,8 @@ __device__ __forceinline__ void field_scatter_level(const NsrLevel &lv, ScatterQ
             // dedupe-table lookup issued NOW (it only needs the key) so that the DPP scan below hides the
             // LDS latency.  x-neighbouring rows differ in their low bits: they never evict each other.
             hsh[x] = key[x] & (SCQ_SEEN - 1);
-            seen_r[x] = q.seen_row[hsh[x]];
             seen_j[x] = q.seen_idx[hsh[x]];
+            seen_r[x] = q.rows[seen_j[x] & SCQ_MASK];      // stale or recycled slots fail the window test below
             const float w = wsel[x][pr & 1] * wz[pr >> 1];
             v[x] = make_float4(w * gd0, w * gd1, w * gc0, w * gc1);
             m[x] = (dpp_shr1_u(key[x]) != key[x]) ? 0.0f : 1.0f;
@@ -344,14 +350,12 @@ __device__ __forceinline__ void field_scatter_level(const NsrLevel &lv, ScatterQ
             const int slot = idx0 & SCQ_MASK;
             q.rows[slot] = key[0];
             q.vals[slot] = v[0];
-            q.seen_row[hsh[0]] = key[0];
             q.seen_idx[hsh[0]] = idx0;
         }
         if (push[1]) {
             const int slot = idx1 & SCQ_MASK;
             q.rows[slot] = key[1];
             q.vals[slot] = v[1];
-            q.seen_row[hsh[1]] = key[1];
             q.seen_idx[hsh[1]] = idx1;
         }
         q.tail += (int)__popcll(mask0) + (int)__popcll(mask1);
@@ -391,9 +395,9 @@ k_field_bwd(FieldBwdArgs b) {
                       (size_t)wave * BWD_QUEUE_BYTES_PER_WAVE;
         q.vals = reinterpret_cast<float4 *>(qbase);
         q.rows = reinterpret_cast<uint32_t *>(qbase + SCQ_CAP * 16);
-        q.seen_row = reinterpret_cast<uint32_t *>(qbase + SCQ_CAP * 20);
-        q.seen_idx = reinterpret_cast<int *>(qbase + SCQ_CAP * 20 + SCQ_SEEN * 4);
-        for (int k = lane; k < SCQ_SEEN; k += 64) { q.seen_row[k] = 0xFFFFFFFFu; q.seen_idx[k] = -1; }
+        q.seen_idx = reinterpret_cast<int *>(qbase + SCQ_CAP * 20);
+        for (int k = lane; k < SCQ_SEEN; k += 64) q.seen_idx[k] = -1;
+        for (int k = lane; k < SCQ_CAP; k += 64) q.rows[k] = 0u;        // keys are row + 1: 0 matches nothing
         q.head = q.tail = 0;
     }
     const bool td = b.train_density != 0, tc = b.train_color != 0;
@@ -448,9 +452,12 @@ k_field_bwd(FieldBwdArgs b) {
         }
         return r;
     };
-    const uint32_t tstep = BWD_THREADS / 64;
+    // Each wave walks a CONTIGUOUS quarter of the block's tiles: consecutive tiles continue the same ray,
+    // so the rows of its coarse and middle levels recur and merge with records still held in the ring.
+    const uint32_t wchunk = (t_end > t_begin ? (t_end - t_begin + BWD_THREADS / 64 - 1) / (BWD_THREADS / 64) : 0u);
+    const uint32_t w_begin = min(t_begin + wave * wchunk, t_end), w_end = min(w_begin + wchunk, t_end);
     TileIn cur;
-    if (t_begin + wave < t_end) cur = load_tile(t_begin + wave);
+    if (w_begin < w_end) cur = load_tile(w_begin);
 
 #ifdef NSR_ABL_STATS
     unsigned long long tacc[4] = {0, 0, 0, 0};
@@ -460,7 +467,7 @@ k_field_bwd(FieldBwdArgs b) {
 #define NSR_TICK(var) do { } while (0)
 #define NSR_TACC(i, a, c) do { } while (0)
 #endif
-    for (uint32_t tile = t_begin + wave; tile < t_end; tile += tstep) {
+    for (uint32_t tile = w_begin; tile < w_end; tile++) {
         NSR_TICK(tk0);
 #ifdef NSR_ABL_STATS
         __builtin_amdgcn_s_waitcnt(0);
@@ -482,7 +489,7 @@ k_field_bwd(FieldBwdArgs b) {
         if (!a.feats) field_encode<TT, CD, false>(lds_lv, tables, u0, u1, u2, live, g, cur.xd, cur.xc);
 
         // paced drain of the previous tile's records: SCQ_PACE(n) issues <= n atomic wave-instructions
-#define SCQ_PACE(n) scq_pace(q, gt1, lane, td, tc, (n), false)
+#define SCQ_PACE(n) scq_pace(q, gt1, lane, td, tc, (n), false, SCQ_KEEP)
         // ================= recompute forward, keeping rounded activations ====================
         s8v xd[1] = {cur.xd}, xc[1] = {cur.xc};
         f4v h[4];
@@ -622,7 +629,7 @@ k_field_bwd(FieldBwdArgs b) {
         // turned into atomics by the pace points of the next tile), so by the next loop top both these loads
         // and the atomics issued ahead of them (vmcnt retires in order) have had the whole scatter to land.
         TileIn nxt = cur;
-        if (tile + tstep < t_end) nxt = load_tile(tile + tstep);
+        if (tile + 1 < w_end) nxt = load_tile(tile + 1);
         NSR_TICK(tk3);
         NSR_TACC(3, tk2, tk3);
         if (td || tc) {
