@@ -1,0 +1,66 @@
+"""Turn the rocprofv3 outputs of the default bench command into the committed profile summaries.
+
+On the GPU box (Measurement):
+  rocprofv3 --kernel-trace --stats -d gpurun_out/prof -o p --output-format csv -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE         -d gpurun_out/pmc_FETCH_SIZE -o p --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline
+  (same for WRITE_SIZE and TCC_EA0_ATOMIC_sum: one counter group per pass, kernel trace only)
+then here:  python tools/make_profiles.py gpurun_out r01
+"""
+import collections, csv, glob, json, os, shutil, sys
+
+
+def find(d, name):
+    hits = glob.glob(os.path.join(d, '**', name), recursive=True)
+    return hits[0] if hits else None
+
+
+def counter_per_launch(d, counter):
+    acc, n = collections.defaultdict(float), collections.Counter()
+    f = find(d, 'p_counter_collection.csv')
+    if not f:
+        return {}
+    for r in csv.DictReader(open(f)):
+        if r['Counter_Name'] != counter:
+            continue
+        k = r['Kernel_Name'].split('(')[0].replace('void ', '').split('<')[0]
+        acc[k] += float(r['Counter_Value'])
+        n[k] += 1
+    return {k: acc[k] / n[k] for k in acc}
+
+
+def main(root, tag, samples_per_launch):
+    os.makedirs('profiles', exist_ok=True)
+    stats = find(os.path.join(root, 'prof'), 'p_kernel_stats.csv')
+    if stats:
+        shutil.copy(stats, 'profiles/%s_bench_kernel_stats.csv' % tag)
+    fetch = counter_per_launch(os.path.join(root, 'pmc_FETCH_SIZE'), 'FETCH_SIZE')
+    write = counter_per_launch(os.path.join(root, 'pmc_WRITE_SIZE'), 'WRITE_SIZE')
+    atom = counter_per_launch(os.path.join(root, 'pmc_TCC_EA0_ATOMIC_sum'), 'TCC_EA0_ATOMIC_sum')
+    out = {
+        'source': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / --pmc TCC_EA0_ATOMIC_sum (three separate passes, '
+                  '--kernel-trace only), python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline (default workload)',
+        'samples_per_launch': samples_per_launch,
+        'correction': 'MI355X_MICROARCH.md HBM section: bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (FETCH_SIZE half-counts '
+                      'wide reads; WRITE_SIZE exact, float atomics are counted as writes); gather access widths are uncalibrated',
+        'kernels': {},
+    }
+    for k in sorted(set(fetch) | set(write)):
+        short = next((n for n in ('k_field_bwd', 'k_field_fwd', 'k_composite_train_fwd', 'k_composite_train_bwd',
+                                  'k_march_count', 'k_march_emit', 'k_adam') if n in k), None)
+        if not short:
+            continue
+        fb, wb = fetch.get(k, 0.0), write.get(k, 0.0)
+        e = {'FETCH_SIZE_KB': round(fb, 1), 'WRITE_SIZE_KB': round(wb, 1),
+             'traffic_bytes_per_launch': int((2 * fb + wb) * 1024),
+             'traffic_bytes_per_sample': round((2 * fb + wb) * 1024 / samples_per_launch, 1)}
+        if k in atom and atom[k] > 0:
+            e['TCC_EA0_ATOMIC_sum_per_launch'] = int(atom[k])
+            e['atomic_requests_per_sample'] = round(atom[k] / samples_per_launch, 2)
+        out['kernels'][short] = e
+    with open('profiles/%s_pmc_traffic.json' % tag, 'w') as f:
+        json.dump(out, f, indent=1)
+    print(json.dumps(out['kernels'].get('k_field_bwd'), indent=1))
+
+
+if __name__ == '__main__':
+    main(sys.argv[1], sys.argv[2], int(sys.argv[3]) if len(sys.argv) > 3 else 48565319)
