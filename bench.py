@@ -201,10 +201,11 @@ def main():
         # ---- roofline of the dominant kernel ------------------------------------------------
         dom = max(prof.items(), key=lambda kv: kv[1][1])[0] if prof else None
         tb = 2 if args.table_dtype == 'f16' else 4
-        # algorithmic bytes per sample (SURVEY 8d / DESIGN.md): gather = 2 enc x 16 lvl x 8 corners x 2 feat x tb
-        # = 512 x tb; backward = the same gather again (recompute) + read-modify-write of the same 512
-        # fp32 gradient elements (2 x 2048 B)
-        bytes_per_sample = {'field_fwd': 512 * tb, 'field_bwd': 512 * tb + 2 * 512 * 4}
+        # algorithmic bytes per sample (SURVEY 8d / DESIGN.md): forward gather = 2 enc x 16 lvl x 8 corners x
+        # 2 feat x tb = 512 x tb; backward = read-modify-write of the same 512 fp32 gradient elements
+        # (2 x 2048 B) + either the 128 B of encoded features the forward saved or the gather again
+        saved = bool(getattr(model, 'save_features', False))
+        bytes_per_sample = {'field_fwd': 512 * tb, 'field_bwd': 2 * 512 * 4 + (128 if saved else 512 * tb)}
         roofline = None
         # HBM traffic per launch from the PMC passes of profiles/ (separate rocprofv3 --pmc FETCH_SIZE /
         # --pmc WRITE_SIZE runs of this same command, corrected as MI355X_MICROARCH.md prescribes);
