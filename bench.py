@@ -46,6 +46,9 @@ def parse():
     ap.add_argument('--compute-dtype', choices=['f16', 'bf16'], default='f16')
     ap.add_argument('--samples-cap', type=int, default=160, help='sample-buffer capacity in samples per ray')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--graph', action='store_true',
+                    help='replay the render+loss+backward part of the step as one captured hipGraph (no per-kernel '
+                         'event timing, so no roofline object): for the small-batch series')
     ap.add_argument('--cpu-budget-s', type=float, default=20.0)
     ap.add_argument('--seed', type=int, default=69420)
     return ap.parse_args()
@@ -158,14 +161,25 @@ def main():
     total_samples = torch.zeros(1, dtype=torch.int64, device=dev)
     overflow = torch.zeros(1, dtype=torch.int64, device=dev)
 
+    def loss_fn(out, pix):
+        mse = torch.mean((out['rgb_map'] - target_rgb[pix]) ** 2)
+        ce = torch.nn.functional.cross_entropy(out['classes'], target_cls[pix]) * 1e-3
+        return (mse + ce) * (loss_scale / world)
+
+    graphed = None
+    if args.graph:
+        from nerfstyle_amd.graph import GraphedRenderStep
+        graphed = GraphedRenderStep(r, n_rays, loss_fn)
+
     def step(it):
         frame = (it * 7 + rank) % poses.shape[0]
         pix = torch.randperm(npix, device=dev, generator=gen)[:n_rays]
-        out = r.render(poses[frame], None, training=True, pix_subset=pix)
-        mse = torch.mean((out['rgb_map'] - target_rgb[pix]) ** 2)
-        ce = torch.nn.functional.cross_entropy(out['classes'], target_cls[pix]) * 1e-3
-        loss = (mse + ce) * (loss_scale / world)
-        loss.backward()
+        if graphed is not None:
+            loss = graphed(poses[frame], pix)
+        else:
+            out = r.render(poses[frame], None, training=True, pix_subset=pix)
+            loss = loss_fn(out, pix)
+            loss.backward()
         if world > 1:
             P.sync_gradients(model)
         opt.param_groups[0]['lr'] = exp_lr(1e-2, it, 30000)
@@ -180,7 +194,7 @@ def main():
     total_samples.zero_()
     overflow.zero_()
     profiling.reset()
-    profiling.enabled = True
+    profiling.enabled = not args.graph      # event records cannot be captured into a graph
     P.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()

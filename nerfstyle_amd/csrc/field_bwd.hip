@@ -745,9 +745,17 @@ int nsr_field_backward(const nsr_field_desc *desc, const void *tables, const flo
 #endif
 #define NSR_BWD_LAUNCH(TT, CD)                                                                                \
     do {                                                                                                       \
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_field_bwd<TT, CD>),                          \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)BWD_LDS_BYTES) != hipSuccess) \
-            return NSR_ERR_LAUNCH;                                                                             \
+        /* once per process and instantiation (idempotent, so a race is harmless): keeps the call free of   */ \
+        /* non-stream API calls, e.g. while the caller captures a hipGraph                                   */ \
+        static bool lds_attr_set[64] = {};                                                                     \
+        int dev_ = 0;                                                                                          \
+        (void)hipGetDevice(&dev_);                                                                             \
+        if (!lds_attr_set[dev_ & 63]) {                                                                                 \
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_field_bwd<TT, CD>),                      \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)BWD_LDS_BYTES) != hipSuccess) \
+                return NSR_ERR_LAUNCH;                                                                         \
+            lds_attr_set[dev_ & 63] = true;                                                                            \
+        }                                                                                                      \
         hipLaunchKernelGGL((k_field_bwd<TT, CD>), grid, block, BWD_LDS_BYTES, s, b);                           \
         NSR_ABL_REPORT();                                                                                      \
         return nsr_launch_status();                                                                            \

@@ -1,0 +1,76 @@
+"""hipGraph capture of the render + loss + backward part of a training step.
+
+The training path is free of host synchronisation (march compaction counts stay on the device, the
+field kernels split their tiles from the device-side count), so the whole forward and backward can be
+captured once with torch.cuda.CUDAGraph (hipGraph on ROCm) and replayed: one graph launch instead of
+~40 kernel launches and their host-side bookkeeping.  What it buys is launch overhead, i.e. it matters
+for the reference's 4096-ray steps, not for full-frame steps.  The optimiser step stays outside the
+graph: its learning rate and step count are kernel scalars.
+
+Reference call stack this replaces: trainers/base.py:367-426 (one `calc_loss` + `backward`)."""
+from typing import Callable, Dict
+
+import torch
+
+from .renderer import Renderer
+
+
+class GraphedRenderStep:
+    """graph = GraphedRenderStep(renderer, n_rays, loss_fn); loss = graph(pose, pix)
+
+    loss_fn(output_dict, pix) -> scalar loss tensor; it must index any per-pixel targets with the `pix`
+    tensor it is given (a static buffer refilled before every replay) and must not synchronise.
+    Gradients accumulate into model.arena.grad exactly as in eager mode."""
+
+    def __init__(self, renderer: Renderer, n_rays: int, loss_fn: Callable[[Dict[str, torch.Tensor], torch.Tensor], torch.Tensor],
+                 warmup: int = 2):
+        assert not renderer.update_occ, 'occupancy updates run on their own schedule: call update_state() between replays'
+        self.r = renderer
+        dev = renderer.device
+        self.pose = torch.zeros(4, 4, dtype=torch.float32, device=dev)
+        self.pose[:3, :3] = torch.eye(3, device=dev)
+        self.pix = torch.arange(n_rays, dtype=torch.int64, device=dev)
+        self.loss_fn = loss_fn
+        self.graph = None
+        self.loss = None
+        self._warmup = warmup
+
+    def _body(self):
+        out = self.r.render(self.pose, None, training=True, pix_subset=self.pix)
+        loss = self.loss_fn(out, self.pix)
+        loss.backward()
+        return loss.detach()
+
+    def capture(self, pose: torch.Tensor, pix: torch.Tensor):
+        self.pose.copy_(pose)
+        self.pix.copy_(pix)
+        model = self.r.model
+        model._ensure_grad()
+        # warm-up on a side stream (allocator pools, lazy initialisation), as torch.cuda.graphs asks
+        s = torch.cuda.Stream(device=self.r.device)
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(self._warmup):
+                self._body()
+        torch.cuda.current_stream().wait_stream(s)
+        model.arena.grad.zero_()           # the warm-up passes accumulated gradients
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.loss = self._body()
+        self._counter = self.r._last_counter   # the captured march's counter (graph-pool memory, refilled by every replay)
+        model.arena.grad.zero_()           # capture does not execute, but keep the contract explicit
+        return self
+
+    def __call__(self, pose: torch.Tensor, pix: torch.Tensor) -> torch.Tensor:
+        if self.graph is None:
+            self.capture(pose, pix)
+        self.pose.copy_(pose)
+        self.pix.copy_(pix)
+        self.graph.replay()
+        self.r._last_counter = self._counter
+        return self.loss
+
+    @property
+    def counter(self):
+        """device-side (samples, rays) counter of the captured march"""
+        return self._counter

@@ -265,8 +265,11 @@ class StyleTCNerf(nn.Module):
         d.num_classes = self.class_dim
         d.table_dtype = L.dt(self.table_dtype)
         d.compute_dtype = L.dt(self.compute_dtype)
-        mn = self.bounds_bbox.min_pt.detach().cpu().tolist()
-        sz = self.bounds_bbox.size.detach().cpu().tolist()
+        # host copy of the (constant) bounding box, read back once: a per-call .cpu() would be a device
+        # synchronisation in the middle of an otherwise sync-free step
+        if getattr(self, '_bbox_host', None) is None:
+            self._bbox_host = (self.bounds_bbox.min_pt.detach().cpu().tolist(), self.bounds_bbox.size.detach().cpu().tolist())
+        mn, sz = self._bbox_host
         for i in range(3):
             d.bbox_min[i] = mn[i]
             d.bbox_size[i] = sz[i]

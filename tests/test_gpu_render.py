@@ -293,3 +293,38 @@ def test_reconstruction_training_learns_with_occupancy_updates(O, dev):
         out = r.render(pose, None, training=False, pix_subset=eval_pix)
     acc = float((out['classes'].argmax(1) == tcls[eval_pix]).float().mean())
     assert acc > 0.5, acc                                # 4 quadrant classes, chance = 0.25
+
+
+def test_graph_captured_step_equals_eager_step(O, dev):
+    """hipGraph capture of render + loss + backward (nerfstyle_amd/graph.py): replaying the graph with
+    new pose / pixel contents gives the eager step's loss and gradients (tolerance: the table-gradient
+    atomics are order-free, fp32 sums differ in the last bits)."""
+    from nerfstyle_amd.graph import GraphedRenderStep
+    r, ref, poses, intr, bits = _setup(dev, cap=192)
+    m = r.model
+    n = 2048
+    g = torch.Generator(device=dev)
+    g.manual_seed(3)
+    target = torch.rand(intr.w * intr.h, 3, device=dev, generator=g)
+
+    def loss_fn(out, pix):
+        return torch.mean((out['rgb_map'] - target[pix]) ** 2) + 1e-3 * out['classes'].square().mean()
+
+    step = GraphedRenderStep(r, n, loss_fn)
+    pose_t = torch.tensor(poses, device=dev)
+    pix0 = torch.randperm(intr.w * intr.h, device=dev, generator=g)[:n]
+    step.capture(pose_t[0], pix0)
+    for k in (1, 5):                                  # replays with contents that differ from the capture
+        pix = torch.randperm(intr.w * intr.h, device=dev, generator=g)[:n]
+        m.arena.grad.zero_()
+        loss_g = step(pose_t[k], pix).clone()
+        grad_g = m.arena.grad.clone()
+        cnt_g = step.counter.clone()
+        m.arena.grad.zero_()
+        out = r.render(pose_t[k], None, training=True, pix_subset=pix)
+        loss_e = loss_fn(out, pix)
+        loss_e.backward()
+        assert int(cnt_g[0]) == int(r._last_counter[0]) > n
+        assert abs(float(loss_g) - float(loss_e.detach())) <= 1e-6 * abs(float(loss_e.detach()))
+        assert float(grad_g.abs().max()) > 0
+        assert rel_l2(grad_g.cpu().numpy(), m.arena.grad.cpu().numpy()) < 1e-4
