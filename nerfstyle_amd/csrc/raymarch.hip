@@ -328,6 +328,7 @@ k_march_emit(const float *__restrict__ rays_o, const float *__restrict__ rays_d,
 // compositing (training)
 // ---------------------------------------------------------------------------------------------
 #define RM_MAXC 16
+#define RM_CU 8u      // composite steps whose loads are issued together
 
 // Training composite, coalesced form.  The reference runs one thread per ray over [M, C] arrays
 // (raymarching.cu:806-879, 904-986): every load of a wave touches 64 different lines (measured
@@ -354,16 +355,32 @@ k_composite_train_fwd(const float *__restrict__ sigmas, const float *__restrict_
         const float *s = sigmas + offset;
         const float *rgb = rgbs + (size_t)offset * C + (has_ch ? ch : 0);
         const float *dl = deltas + (size_t)offset * 4;
-        for (uint32_t step = 0; step < num_steps; step++) {
-            const float2 dd = is_ndc ? *reinterpret_cast<const float2 *>(dl + step * 4 + 2) : *reinterpret_cast<const float2 *>(dl + step * 4);
-            const float alpha = 1.0f - __expf(-s[step] * dd.x);
-            const float weight = alpha * T;
-            if (has_ch) acc += weight * rgb[(size_t)step * C];
-            t += dd.y;
-            d += weight * t;
-            ws += weight;
-            T *= 1.0f - alpha;
-            if (T < T_thresh) break;   // :862
+        // RM_CU steps per trip: their loads are issued together (indices clamped into the ray, so the
+        // speculation past an early stop stays in bounds) -- the recurrence on T is serial, the memory
+        // latency in front of it need not be paid once per step
+        bool stop = false;
+        for (uint32_t base = 0; base < num_steps && !stop; base += RM_CU) {
+            float sv[RM_CU], cv[RM_CU];
+            float2 dv[RM_CU];
+#pragma unroll
+            for (uint32_t u = 0; u < RM_CU; u++) {
+                const uint32_t st = min(base + u, num_steps - 1);
+                dv[u] = is_ndc ? *reinterpret_cast<const float2 *>(dl + st * 4 + 2) : *reinterpret_cast<const float2 *>(dl + st * 4);
+                sv[u] = s[st];
+                cv[u] = rgb[(size_t)st * C];
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < RM_CU; u++) {
+                if (base + u >= num_steps) { stop = true; break; }
+                const float alpha = 1.0f - __expf(-sv[u] * dv[u].x);
+                const float weight = alpha * T;
+                if (has_ch) acc += weight * cv[u];
+                t += dv[u].y;
+                d += weight * t;
+                ws += weight;
+                T *= 1.0f - alpha;
+                if (T < T_thresh) { stop = true; break; }   // :862
+            }
         }
     }
     if (ch == 0) {
@@ -413,19 +430,33 @@ k_composite_train_bwd(const float *__restrict__ grad_weights_sum, const float *_
     // lanes of a group run the same trip count (same ray), different groups of a wave do not: the
     // cross-lane sum uses DPP-free shuffles restricted to the group, executed by every live group
     uint32_t step = 0;
-    for (; step < steps; step++) {
-        const float delta = is_ndc ? dl[step * 4 + 2] : dl[step * 4 + 0];
-        const float alpha = 1.0f - __expf(-s[step] * delta);
-        const float weight = alpha * T;
-        const float c = has_ch ? rgb[(size_t)step * C] : 0.0f;
-        buf += weight * c;
-        T *= 1.0f - alpha;
-        if (T < T_thresh) break;   // :961
-        if (has_ch) grgb[(size_t)step * C] = gim * weight;
-        float gsum = has_ch ? gim * (T * c - (im - buf)) : 0.0f;
+    bool stop = false;
+    for (uint32_t base = 0; base < steps && !stop; base += RM_CU) {
+        float sv[RM_CU], cv[RM_CU], dlv[RM_CU];
 #pragma unroll
-        for (int off = LPR / 2; off >= 1; off >>= 1) gsum += __shfl_xor(gsum, off, LPR);
-        if (ch == 0) gs[step] = delta * (gsum + gws * (1 - ws_final));
+        for (uint32_t u = 0; u < RM_CU; u++) {
+            const uint32_t st = min(base + u, steps - 1);
+            dlv[u] = is_ndc ? dl[st * 4 + 2] : dl[st * 4 + 0];
+            sv[u] = s[st];
+            cv[u] = has_ch ? rgb[(size_t)st * C] : 0.0f;
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < RM_CU; u++) {
+            if (base + u >= steps) { stop = true; break; }
+            const float delta = dlv[u];
+            const float alpha = 1.0f - __expf(-sv[u] * delta);
+            const float weight = alpha * T;
+            const float c = cv[u];
+            buf += weight * c;
+            T *= 1.0f - alpha;
+            if (T < T_thresh) { stop = true; break; }   // :961
+            if (has_ch) grgb[(size_t)step * C] = gim * weight;
+            float gsum = has_ch ? gim * (T * c - (im - buf)) : 0.0f;
+#pragma unroll
+            for (int off = LPR / 2; off >= 1; off >>= 1) gsum += __shfl_xor(gsum, off, LPR);
+            if (ch == 0) gs[step] = delta * (gsum + gws * (1 - ws_final));
+            step++;
+        }
     }
     // samples at and after the early stop keep the zero gradient the reference pre-fills
     if (zero_fill) {
