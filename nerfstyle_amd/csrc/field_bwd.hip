@@ -32,7 +32,8 @@ constexpr int BW_D1T = 13312;    // d1^T  [32 x 64]  4 frag32
 constexpr int BW_TOTAL = 15360;
 
 constexpr int BWD_THREADS = 256;
-constexpr size_t BWD_QUEUE_BYTES_PER_WAVE = 1024 * 16 + 1024 * 4 + 512 * 8;
+// per wave: record ring (1024 x {float4 sums, row}) + the [16 levels][16 samples] float4 gradient staging buffer
+constexpr size_t BWD_QUEUE_BYTES_PER_WAVE = 1024 * 16 + 1024 * 4 + 16 * 16 * 16;
 constexpr size_t BWD_LDS_BYTES = (size_t)FW_TOTAL * 2 + (size_t)BW_TOTAL * 2 + 16 * sizeof(NsrLevel) +
                                  (BWD_THREADS / 64) * BWD_QUEUE_BYTES_PER_WAVE;
 
@@ -44,7 +45,6 @@ struct FieldBwdArgs {
     float *grad_mlp;
     int train_density, train_color;
     uint32_t nc;
-    uint32_t fast_levels;   // bit l: level l is hashed and its size is a power of two
 };
 
 template <int CD>
@@ -116,21 +116,20 @@ __device__ __forceinline__ void field_mask_pack(const f4v (&gacc)[4], const s8v 
 }
 
 // ---- table scatter ----------------------------------------------------------------------------
-// Global float atomics are priced per 64-byte request at the memory side (~1e10 requests/s chip
-// wide), not per byte: 64 lanes adding one dword each to 64 different rows cost 64 requests.  The
-// naive scatter (4 dword atomics per corner per lane) is 512 requests per sample and ran the whole
-// backward at 21 M samples/s.  Two reductions of the request count, both exact up to fp32
-// summation order:
-//   1. the 16 lanes of a DPP row hold 16 CONSECUTIVE samples of one level; consecutive samples of
-//      a ray share cells on the coarse and middle levels, so equal rows form runs: a segmented
-//      scan over the row (v_mov_dpp row_shr) sums each run and only its last lane emits a record;
-//   2. records {row, d0, d1, c0, c1} go through a small per-wave LDS queue and are drained 16 per
-//      wave-instruction with 4 lanes per record, so the four dwords of an interleaved row leave as
-//      ONE 16-byte request instead of four 4-byte ones.
-//   3. the queue is a RING drained in small paced bursts spread over the NEXT tile's compute
-//      (SCQ_PACE): atomics are fire-and-forget, but a burst of ~45 back-to-back wave-instructions
-//      blocks at issue once the memory side is saturated, and with one wave per SIMD a blocked
-//      wave is an idle SIMD.  Pacing lets the atomic service time hide under the MFMA/VALU work.
+// Global float atomics are priced per 64-byte request at the memory side (21 G requests/s chip wide,
+// tools/atomic_*_bench.hip), not per byte: 64 lanes adding one dword each to 64 different rows cost 64
+// requests.  The naive scatter (4 dword atomics per corner per lane) is 512 requests per sample and ran the
+// whole backward at 21 M samples/s.  What is done instead, exact up to fp32 summation order:
+//   1. consecutive samples of a ray share table rows (same cell, or the face shared with the next cell) on
+//      all but the finest levels: field_scatter_seq keeps every corner's open run in registers and emits one
+//      record {row, d0, d1, c0, c1} per finished run (128 corner touches -> ~30 records per sample);
+//   2. records go through a per-wave LDS ring and are drained 16 per wave-instruction with 4 lanes per
+//      record: the four dwords of an interleaved row leave as ONE 16-byte request, and the two x corners
+//      of a lane, adjacent in the ring, usually share a 64-byte line (one request);
+//   3. the ring is drained in small paced bursts spread over the NEXT tile's dgrad / wgrad section
+//      (SCQ_PACE): atomics are fire-and-forget, but a burst of ~45 back-to-back wave-instructions blocks
+//      at issue once the memory side is saturated, and with one wave per SIMD a blocked wave is an idle
+//      SIMD; and nothing may wait on vmcnt while fresh atomics are in flight (see the loop comment).
 #ifdef NSR_ABL_STATS
 __device__ unsigned long long g_stats[8];
 #define NSR_STAT_ALWAYS(i, n) do { if (lane == 0) atomicAdd(&g_stats[i], (unsigned long long)(n)); } while (0)
@@ -151,42 +150,14 @@ __device__ float g_priv[NSR_ABL_PRIV_COPIES][(NSR_ABL_PRIV_ROWS + 8) * 4];
 constexpr int SCQ_CAP = 1024;    // records per wave (power of two)
 constexpr int SCQ_MASK = SCQ_CAP - 1;
 #ifndef NSR_SCQ_KEEP
-#define NSR_SCQ_KEEP 512
+#define NSR_SCQ_KEEP 0
 #endif
-constexpr int SCQ_KEEP = NSR_SCQ_KEEP;     // records the paced drain leaves in the ring for cross-tile merging
-constexpr int SCATTER_PACE = 0;  // atomic wave-instructions per corner pair in the last two scatter calls (measured: 2 is slower than 0)
-constexpr int SCQ_SEEN = 1024;   // direct-mapped "row -> record still in the ring" table per wave (record index only:
-                                 // the row is verified against the ring itself)
+constexpr int SCQ_KEEP = NSR_SCQ_KEEP;     // records the paced drain leaves in the ring (experiments only)
 struct ScatterQueue {
     uint32_t *rows;              // [SCQ_CAP]
     float4 *vals;                // [SCQ_CAP]
-    int *seen_idx;               // [SCQ_SEEN] (monotonic) index of the last record pushed under this hash
     int head, tail;              // wave-uniform, monotonically increasing record indices
 };
-
-// DPP row shifts with bound_ctrl:1 -- lanes shifted in from outside the 16-lane row read 0, so no
-// "old" register has to be initialised and the move can fold into the consuming VOP2
-template <int K>
-__device__ __forceinline__ float dpp_shr_f(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x110 + K, 0xF, 0xF, true));
-}
-__device__ __forceinline__ uint32_t dpp_shr1_u(uint32_t v) {
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true);
-}
-__device__ __forceinline__ uint32_t dpp_shl1_u(uint32_t v) {
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x101, 0xF, 0xF, true);
-}
-
-// one Hillis-Steele step of a segmented inclusive scan over a 16-lane DPP row.  m is 1.0 while the
-// lanes K to the left still belong to this lane's run, 0.0 once a run head lies in between; the zero
-// shifted in from outside the row ends every run at the row boundary.
-template <int K>
-__device__ __forceinline__ void seg_step(float4 &v, float &m) {
-    const float a = dpp_shr_f<K>(v.x), b = dpp_shr_f<K>(v.y), c = dpp_shr_f<K>(v.z), d = dpp_shr_f<K>(v.w);
-    const float mu = dpp_shr_f<K>(m);
-    v.x = fmaf(a, m, v.x); v.y = fmaf(b, m, v.y); v.z = fmaf(c, m, v.z); v.w = fmaf(d, m, v.w);
-    m *= mu;
-}
 
 // N full groups of 16 records: all LDS reads first, then the N atomic wave-instructions (4 lanes per
 // record: the 4 dwords of an interleaved row leave as ONE 16-byte request).  With one wave per SIMD an
@@ -243,124 +214,131 @@ __device__ __forceinline__ void scq_pace(ScatterQueue &q, float *__restrict__ gt
     __builtin_amdgcn_wave_barrier();
 }
 
-// One level, all 8 corners, for the 16-sample tile (this lane = one sample of one level group).
-// FAST: every level handled by this call (one per 16-lane group) is hashed with a power-of-two size
-// (wave-uniform, from the host's level table), so the row is (x ^ y*P1 ^ z*P2) & (size-1): the same
-// value nsr_grid_row computes, without the per-lane dense/hash select and the invariant-divisor modulo.
-// Dead lanes arrive with u = 0 and zero gradients: they map to cell 0 with an all-zero value, extend a
-// neighbour's run harmlessly or form a zero run that is never pushed.
-template <bool FAST, int PACE>
-__device__ __forceinline__ void field_scatter_level(const NsrLevel &lv, ScatterQueue &q, float *__restrict__ gt1, float u0, float u1,
-                                                    float u2, float gd0, float gd1, float gc0, float gc1, bool swapx,
-                                                    int lane, bool td, bool tc) {
+// ---------------------------------------------------------------------------------------------------------
+// Sequential run tracker.  Lane = (level l = lane >> 2,
+// y/z corner pair p = lane & 3) owns the two x corners of that pair as two STREAMS A (x0) and B (x0 + 1) and
+// walks the tile's 16 samples in order, keeping for each stream the open run {row key, 4 gradient sums} in
+// registers -- across tiles too, a wave's tiles being consecutive samples.  A sample that stays in the cell
+// adds to both runs; one that moves exactly one cell along one axis hands the still-needed runs over in
+// registers (x: between the lane's own two streams; y, z: from the quad neighbour lane p^1 / p^2 by DPP
+// quad_perm) -- the decision is geometric (same grid corner => same row), identical in the four lanes of a
+// level, so every finished run is emitted exactly once; anything else closes both runs.  Per sample step
+// ~180 instructions for 128 corner touches (the first version of this kernel, a DPP segmented scan over the 16
+// samples of a level with a hashed "row still in the ring" table, needed ~4000 per tile more).
+struct SeqState {
+    uint32_t c0, c1, c2;     // cell of the previous sample at this lane's level
+    uint32_t kA, kB;         // row + 1 of the open runs (0: none)
+    float4 aA, aB;           // their gradient sums {d0, d1, c0, c1}
+};
+
+__device__ __forceinline__ float4 seq_quad(const float4 &v, bool n1) {
+    // value of quad neighbour p^1 (n1) or p^2
+    float4 r;
+    if (n1) {
+        r.x = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v.x), 0xB1, 0xF, 0xF, true));
+        r.y = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v.y), 0xB1, 0xF, 0xF, true));
+        r.z = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v.z), 0xB1, 0xF, 0xF, true));
+        r.w = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v.w), 0xB1, 0xF, 0xF, true));
+    } else {
+        r.x = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v.x), 0x4E, 0xF, 0xF, true));
+        r.y = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v.y), 0x4E, 0xF, 0xF, true));
+        r.z = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v.z), 0x4E, 0xF, 0xF, true));
+        r.w = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v.w), 0x4E, 0xF, 0xF, true));
+    }
+    return r;
+}
+
+__device__ __forceinline__ float4 seq_sel(bool c, const float4 &a, const float4 &b) {
+    return make_float4(c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z, c ? a.w : b.w);
+}
+
+__device__ __forceinline__ bool seq_nonzero(const float4 &v) {
+    return ((__float_as_uint(v.x) | __float_as_uint(v.y) | __float_as_uint(v.z) | __float_as_uint(v.w)) << 1) != 0u;
+}
+
+// pushes the (up to two, adjacent) records of every lane
+__device__ __forceinline__ void seq_push(ScatterQueue &q, bool pA, uint32_t kA, const float4 &vA, bool pB, uint32_t kB,
+                                         const float4 &vB) {
+    const unsigned long long mask0 = __ballot(pA), mask1 = __ballot(pB);
+    const int below = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask0, 0u)) +
+                      (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask1, 0u));
+    const int idx0 = q.tail + below, idx1 = idx0 + (pA ? 1 : 0);
+    if (pA) { const int slot = idx0 & SCQ_MASK; q.rows[slot] = kA; q.vals[slot] = vA; }
+    if (pB) { const int slot = idx1 & SCQ_MASK; q.rows[slot] = kB; q.vals[slot] = vB; }
+    q.tail += (int)__popcll(mask0) + (int)__popcll(mask1);
+}
+
+// One tile.  G: this wave's [16 levels][16 samples] float4 staging buffer in LDS; (u0,u1,u2): this lane's
+// SAMPLE (lane & 15) position, 0 for dead samples; sg[i]: its gradients for level lvl[i] (zero when dead).
+__device__ __forceinline__ void field_scatter_seq(SeqState &st, const NsrLevel *__restrict__ lds_lv, float4 *__restrict__ G,
+                                                  ScatterQueue &q, float *__restrict__ gt1, float u0, float u1, float u2,
+                                                  const float4 (&sg)[4], int lane, bool td, bool tc) {
 #ifdef NSR_ABL_NO_SCATTER
-    if (lv.resolution != 0xFFFFFFFFu) return;
+    if (lane >= 0) return;
 #endif
-    float f[3];
-    uint32_t c[3];
-    nsr_grid_locate(u0, lv.resolution, 1, f[0], c[0]);
-    nsr_grid_locate(u1, lv.resolution, 1, f[1], c[1]);
-    nsr_grid_locate(u2, lv.resolution, 1, f[2], c[2]);
-    // (wx*wy)*wz, the product order of the forward interpolation
-    const float wxy[4] = {(1 - f[0]) * (1 - f[1]), f[0] * (1 - f[1]), (1 - f[0]) * f[1], f[0] * f[1]};
-    const float wz[2] = {1 - f[2], f[2]};
-    const uint32_t hy[2] = {c[1] * 2654435761u, (c[1] + 1) * 2654435761u};
-    const uint32_t hz[2] = {c[2] * 805459861u, (c[2] + 1) * 805459861u};
-    const uint32_t off1 = lv.offset + 1u, msk = lv.size - 1u;
-    // stream 0 = the TRAILING x corner with respect to the ray's direction of travel, stream 1 = the leading
-    // one: when the ray steps one cell in x, lane s+1's trailing corner is lane s's leading corner
-    const uint32_t cx[2] = {c[0] + (swapx ? 1u : 0u), c[0] + (swapx ? 0u : 1u)};
-    const float wsel[2][2] = {{swapx ? wxy[1] : wxy[0], swapx ? wxy[3] : wxy[2]}, {swapx ? wxy[0] : wxy[1], swapx ? wxy[2] : wxy[3]}};
-    // Corners are handled as x / x+1 PAIRS and a lane's two records are adjacent in the ring: the hash
-    // prime for x is 1, so the two rows are neighbours (same 64-byte line 3 times out of 4) and leave in
-    // the same 16-record atomic instruction, where the memory side merges them into one request
-    // (tools/scatter_sim.py: 26.1 -> 19.1 requests per sample on the bench scene).
+    const int s = lane & 15, g = lane >> 4;
+    const int lvl[4] = {2 * g, 2 * g + 1, 8 + 2 * g, 9 + 2 * g};
 #pragma unroll
-    for (uint32_t pr = 0; pr < 4; pr++) {
-        // make room for this pair's (at most 128) records; rare
+    for (int i = 0; i < 4; i++) G[lvl[i] * 16 + s] = sg[i];
+    __builtin_amdgcn_wave_barrier();
+    // this lane's level
+    const int l = lane >> 2, py = lane & 1, pz = (lane >> 1) & 1;
+    const NsrLevel lv = lds_lv[l];
+    const bool hashed = lv.use_hash != 0;
+    const uint32_t mulY = hashed ? 2654435761u : lv.mul[1], mulZ = hashed ? 805459861u : lv.mul[2];
+    const uint32_t off1 = lv.offset + 1u;
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 gnext = G[l * 16];
+#pragma unroll 2
+    for (int step = 0; step < 16; step++) {
+        const float4 gr = gnext;
+        gnext = G[l * 16 + ((step + 1) & 15)];
+        const float su0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, u0), step));
+        const float su1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, u1), step));
+        const float su2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, u2), step));
+        float f0, f1, f2;
+        uint32_t c0, c1, c2;
+        nsr_grid_locate(su0, lv.resolution, 1, f0, c0);
+        nsr_grid_locate(su1, lv.resolution, 1, f1, c1);
+        nsr_grid_locate(su2, lv.resolution, 1, f2, c2);
+        // ---- how did the cell move? (same answer in the 4 lanes of a level) ----
+        const int d0 = (int)(c0 - st.c0), d1 = (int)(c1 - st.c1), d2 = (int)(c2 - st.c2);
+        const bool same = (d0 | d1 | d2) == 0;
+        const bool sx = (d1 | d2) == 0 && (d0 == 1 || d0 == -1);
+        const bool sy = (d0 | d2) == 0 && (d1 == 1 || d1 == -1);
+        const bool sz = (d0 | d1) == 0 && (d2 == 1 || d2 == -1);
+        const bool sxp = sx && d0 == 1, sxm = sx && d0 == -1;
+        // y step up: the lanes of the LOW y corner (py = 0) continue the runs their quad neighbour (py = 1) held
+        const bool takeY = sy && (py == (d1 > 0 ? 0 : 1)), giveY = sy && !takeY;
+        const bool takeZ = sz && (pz == (d2 > 0 ? 0 : 1)), giveZ = sz && !takeZ;
+        // ---- records that end here ----
+        const bool emitA = !same && !sxm && !giveY && !giveZ && seq_nonzero(st.aA);
+        const bool emitB = !same && !sxp && !giveY && !giveZ && seq_nonzero(st.aB);
         if (q.tail - q.head > SCQ_CAP - 128) { NSR_STAT(3, 1); scq_pace(q, gt1, lane, td, tc, 16, false); }
-        uint32_t key[2], hsh[2], seen_r[2];
-        int seen_j[2];
-        float4 v[2];
-        float m[2];
-        bool push[2];
-#pragma unroll
-        for (uint32_t x = 0; x < 2; x++) {
-            // run = consecutive samples with the same table row.  Keys are row + 1, so the zero a DPP shift
-            // reads outside the row never matches; the drain subtracts the 1 through its base pointer.
-            if (FAST) key[x] = off1 + ((cx[x] ^ hy[pr & 1] ^ hz[pr >> 1]) & msk);
-            else key[x] = off1 + nsr_grid_row(lv, cx[x], c[1] + (pr & 1), c[2] + (pr >> 1), 0u);
-            // dedupe-table lookup issued NOW (it only needs the key) so that the DPP scan below hides the
-            // LDS latency.  x-neighbouring rows differ in their low bits: they never evict each other.
-            hsh[x] = key[x] & (SCQ_SEEN - 1);
-            seen_j[x] = q.seen_idx[hsh[x]];
-            seen_r[x] = q.rows[seen_j[x] & SCQ_MASK];      // stale or recycled slots fail the window test below
-            const float w = wsel[x][pr & 1] * wz[pr >> 1];
-            v[x] = make_float4(w * gd0, w * gd1, w * gc0, w * gc1);
-            m[x] = (dpp_shr1_u(key[x]) != key[x]) ? 0.0f : 1.0f;
-            push[x] = dpp_shl1_u(key[x]) != key[x];           // run tail
+        seq_push(q, emitA, st.kA, st.aA, emitB, st.kB, st.aB);
+        NSR_STAT(0, __popcll(__ballot(emitA)) + __popcll(__ballot(emitB)));
+        // ---- runs that continue: where from ----
+        const float4 nA = seq_quad(st.aA, true), nB = seq_quad(st.aB, true);
+        const float4 mA = seq_quad(st.aA, false), mB = seq_quad(st.aB, false);
+        const float4 baseA = seq_sel(same, st.aA, seq_sel(sxp, st.aB, seq_sel(takeY, nA, seq_sel(takeZ, mA, zero4))));
+        const float4 baseB = seq_sel(same, st.aB, seq_sel(sxm, st.aA, seq_sel(takeY, nB, seq_sel(takeZ, mB, zero4))));
+        // ---- this sample's contribution: (wx*wy)*wz, the product order of the forward interpolation ----
+        const float wy = py ? f1 : 1 - f1, wz = pz ? f2 : 1 - f2;
+        const float wA = ((1 - f0) * wy) * wz, wB = (f0 * wy) * wz;
+        st.aA = make_float4(fmaf(wA, gr.x, baseA.x), fmaf(wA, gr.y, baseA.y), fmaf(wA, gr.z, baseA.z), fmaf(wA, gr.w, baseA.w));
+        st.aB = make_float4(fmaf(wB, gr.x, baseB.x), fmaf(wB, gr.y, baseB.y), fmaf(wB, gr.z, baseB.z), fmaf(wB, gr.w, baseB.w));
+        // ---- keys of the (possibly unchanged) cell: nsr_grid_row for both x corners ----
+        if (!same) {
+            const uint32_t ty = (c1 + (uint32_t)py) * mulY, tz = (c2 + (uint32_t)pz) * mulZ;
+            const uint32_t comb = hashed ? (ty ^ tz) : (ty + tz);
+            const uint32_t iA = hashed ? (c0 ^ comb) : (c0 * lv.mul[0] + comb);
+            const uint32_t iB = hashed ? ((c0 + 1u) ^ comb) : ((c0 + 1u) * lv.mul[0] + comb);
+            const uint32_t tA = __umulhi(lv.magic, iA), tB = __umulhi(lv.magic, iB);
+            const uint32_t qA = (tA + ((iA - tA) >> lv.sh1)) >> lv.sh2, qB = (tB + ((iB - tB) >> lv.sh1)) >> lv.sh2;
+            st.kA = off1 + (iA - qA * lv.size);
+            st.kB = off1 + (iB - qB * lv.size);
+            st.c0 = c0; st.c1 = c1; st.c2 = c2;
         }
-        // leading stream first; where the next lane's trailing row is this lane's leading row (the ray
-        // stepped one cell in x) the finished run sum moves over in registers and continues there, instead
-        // of becoming a second record with the same address in the same atomic instruction
-        const bool absorb = dpp_shr1_u(key[1]) == key[0];      // my trailing run continues lane s-1's leading run
-        const bool absorbed = dpp_shl1_u(key[0]) == key[1];    // my leading run is continued by lane s+1
-#ifndef NSR_ABL_NO_SCAN
-        seg_step<1>(v[1], m[1]); seg_step<2>(v[1], m[1]); seg_step<4>(v[1], m[1]); seg_step<8>(v[1], m[1]);
-        {
-            const float a = dpp_shr_f<1>(v[1].x), b2 = dpp_shr_f<1>(v[1].y), c2 = dpp_shr_f<1>(v[1].z), d = dpp_shr_f<1>(v[1].w);
-            const float t = absorb ? 1.0f : 0.0f;
-            v[0].x = fmaf(a, t, v[0].x); v[0].y = fmaf(b2, t, v[0].y); v[0].z = fmaf(c2, t, v[0].z); v[0].w = fmaf(d, t, v[0].w);
-        }
-        seg_step<1>(v[0], m[0]); seg_step<2>(v[0], m[0]); seg_step<4>(v[0], m[0]); seg_step<8>(v[0], m[0]);
-#endif
-        push[1] = push[1] && !absorbed;
-#pragma unroll
-        for (uint32_t x = 0; x < 2; x++) {
-            // a run whose summed gradient is exactly zero (e.g. samples behind an opaque surface: the
-            // composite backward gives them zero gradient) adds nothing: skip its request
-            const uint32_t any = __float_as_uint(v[x].x) | __float_as_uint(v[x].y) | __float_as_uint(v[x].z) | __float_as_uint(v[x].w);
-            push[x] = push[x] && (any << 1) != 0u;
-#ifdef NSR_ABL_NO_PUSH
-            push[x] = push[x] && m[x] == 12345.f;
-#endif
-#ifdef NSR_ABL_MIN_ROW
-            push[x] = push[x] && key[x] > NSR_ABL_MIN_ROW;
-#endif
-#ifdef NSR_ABL_MAX_ROW
-            push[x] = push[x] && key[x] <= NSR_ABL_MAX_ROW;
-#endif
-#ifndef NSR_ABL_NO_DEDUPE
-            // Exact duplicate addresses are the one thing the atomic path never merges (tools/
-            // atomic_merge_rule.hip), and they are common: face-adjacent cells share 4 of their 8 corner
-            // rows, runs continue across tiles.  If this row was pushed recently and its record is still in
-            // the ring, add into that record instead of emitting another request.
-            if (push[x] && seen_r[x] == key[x] && (uint32_t)(seen_j[x] - q.head) < (uint32_t)(q.tail - q.head)) {
-                float *dst = reinterpret_cast<float *>(q.vals + (seen_j[x] & SCQ_MASK));
-                atomicAdd(dst + 0, v[x].x); atomicAdd(dst + 1, v[x].y); atomicAdd(dst + 2, v[x].z); atomicAdd(dst + 3, v[x].w);
-                push[x] = false;
-            }
-#endif
-        }
-        const unsigned long long mask0 = __ballot(push[0]), mask1 = __ballot(push[1]);
-        const int below = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask0, 0u)) +
-                          (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask1, 0u));
-        const int idx0 = q.tail + below, idx1 = idx0 + (push[0] ? 1 : 0);
-        if (push[0]) {
-            const int slot = idx0 & SCQ_MASK;
-            q.rows[slot] = key[0];
-            q.vals[slot] = v[0];
-            q.seen_idx[hsh[0]] = idx0;
-        }
-        if (push[1]) {
-            const int slot = idx1 & SCQ_MASK;
-            q.rows[slot] = key[1];
-            q.vals[slot] = v[1];
-            q.seen_idx[hsh[1]] = idx1;
-        }
-        q.tail += (int)__popcll(mask0) + (int)__popcll(mask1);
-        NSR_STAT(0, __popcll(mask0) + __popcll(mask1));
-        if (PACE > 0) scq_pace(q, gt1, lane, td, tc, PACE, false);
     }
 }
 
@@ -390,16 +368,21 @@ k_field_bwd(FieldBwdArgs b) {
     const s4v ident = mm_identity_frag<CD>(lane);
     const int nc = (int)b.nc;
     ScatterQueue q;
+    char *qbase_g;
     {
         char *qbase = smem + (size_t)(FW_TOTAL + BW_TOTAL) * 2 + 16 * sizeof(NsrLevel) +
                       (size_t)wave * BWD_QUEUE_BYTES_PER_WAVE;
         q.vals = reinterpret_cast<float4 *>(qbase);
         q.rows = reinterpret_cast<uint32_t *>(qbase + SCQ_CAP * 16);
-        q.seen_idx = reinterpret_cast<int *>(qbase + SCQ_CAP * 20);
-        for (int k = lane; k < SCQ_SEEN; k += 64) q.seen_idx[k] = -1;
+        qbase_g = qbase + SCQ_CAP * 20;
         for (int k = lane; k < SCQ_CAP; k += 64) q.rows[k] = 0u;        // keys are row + 1: 0 matches nothing
         q.head = q.tail = 0;
     }
+    SeqState seq;
+    seq.c0 = seq.c1 = seq.c2 = 0x7FFFFFF0u;
+    seq.kA = seq.kB = 0u;
+    seq.aA = seq.aB = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 *const seqG = reinterpret_cast<float4 *>(qbase_g);        // [16 levels][16 samples] float4 staging, 4 KB
     const bool td = b.train_density != 0, tc = b.train_color != 0;
     float *const gt1 = b.grad_tables - 4;      // ring rows are stored +1 (field_scatter_level)
     // weight-gradient accumulators (60 tiles x 4 regs), resident for the whole launch
@@ -620,9 +603,8 @@ k_field_bwd(FieldBwdArgs b) {
 
         // ================= table scatter =======================================================
         // gxd[t][2*(i&1)+f] is d L / d feature f of level lvl[i] (t = i >> 1): same lane<->level map
-        // as the forward encode.
-        // this tile's scatter: VALU + LDS only (records go to the ring; atomics are issued by the pace
-        // points of the NEXT tile's dgrad / wgrad section), then the next tile's loads
+        // as the forward encode.  The scatter is VALU + LDS only: its records go to the ring and leave as
+        // atomics at the pace points of the NEXT tile's dgrad / wgrad section.
         NSR_TICK(tk2);
         NSR_TACC(1, tk1, tk2);
         // Next tile's loads go out BEFORE this tile's scatter: the scatter touches LDS only (its records are
@@ -633,42 +615,13 @@ k_field_bwd(FieldBwdArgs b) {
         NSR_TICK(tk3);
         NSR_TACC(3, tk2, tk3);
         if (td || tc) {
-            const int lvl[4] = {2 * g, 2 * g + 1, 8 + 2 * g, 9 + 2 * g};
-            // x direction of travel of this lane's ray, from its neighbour sample (any value is correct,
-            // a consistent one lets field_scatter_level chain the runs of x-adjacent cells)
-            const bool swapx = (s == 15 ? u0 - dpp_shr_f<1>(u0) : __builtin_bit_cast(float, dpp_shl1_u(__builtin_bit_cast(uint32_t, u0))) - u0) < 0.f;
-            // levels per call (one per lane group): {0,2,4,6} {1,3,5,7} {8,10,12,14} {9,11,13,15}
-            const uint32_t call_levels[4] = {0x0055u, 0x00AAu, 0x5500u, 0xAA00u};
+            float4 sg[4];
 #pragma unroll
             for (int i = 0; i < 4; i++) {
-                const NsrLevel lv = lds_lv[lvl[i]];
                 const int t = i >> 1, e0 = 2 * (i & 1);
-                // dead lanes carry zero gradients (see field_scatter_level)
-                const float s0 = live ? gxd[t][e0] : 0.f, s1 = live ? gxd[t][e0 + 1] : 0.f;
-                const float s2 = live ? gxc[t][e0] : 0.f, s3 = live ? gxc[t][e0 + 1] : 0.f;
-#ifdef NSR_ABL_NO_MLP
-#define s0 (live ? cur_gsig + 1.f : 0.f)
-#define s1 (live ? cur_gsig + 2.f : 0.f)
-#define s2 (live ? cur_grgb[0] + 1.f : 0.f)
-#define s3 (live ? cur_grgb[1] + 2.f : 0.f)
-#endif
-                // The first two calls issue no atomics: the prefetch above and the atomics of the dgrad /
-                // wgrad pace points land meanwhile.  Then the prefetched registers are touched -- the one
-                // place the compiler has to wait for memory (vmcnt(0): gfx9 counts loads and atomics in one
-                // counter and may not assume an order between them) -- and the last two calls pace atomics
-                // again, which stay in flight across the loop back-edge.
-                if (i == 2)
-                    asm volatile("" ::"v"(nxt.x0), "v"(nxt.x1), "v"(nxt.x2), "v"(nxt.gsig), "v"(nxt.grgb[0]), "v"(nxt.grgb[1]),
-                                 "v"(nxt.grgb[2]), "v"(nxt.grgb[3]), "v"(nxt.xd), "v"(nxt.xc));
-                const bool fast = (b.fast_levels & call_levels[i]) == call_levels[i];
-                if (i < 2) {
-                    if (fast) field_scatter_level<true, 0>(lv, q, gt1, u0, u1, u2, s0, s1, s2, s3, swapx, lane, td, tc);
-                    else field_scatter_level<false, 0>(lv, q, gt1, u0, u1, u2, s0, s1, s2, s3, swapx, lane, td, tc);
-                } else {
-                    if (fast) field_scatter_level<true, SCATTER_PACE>(lv, q, gt1, u0, u1, u2, s0, s1, s2, s3, swapx, lane, td, tc);
-                    else field_scatter_level<false, SCATTER_PACE>(lv, q, gt1, u0, u1, u2, s0, s1, s2, s3, swapx, lane, td, tc);
-                }
+                sg[i] = live ? make_float4(gxd[t][e0], gxd[t][e0 + 1], gxc[t][e0], gxc[t][e0 + 1]) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
+            field_scatter_seq(seq, lds_lv, seqG, q, gt1, live ? u0 : 0.f, live ? u1 : 0.f, live ? u2 : 0.f, sg, lane, td, tc);
         }
         NSR_TICK(tk4);
         NSR_TACC(2, tk3, tk4);
@@ -677,14 +630,15 @@ k_field_bwd(FieldBwdArgs b) {
 #ifdef NSR_ABL_STATS
     for (int i = 0; i < 4; i++) NSR_STAT_ALWAYS(4 + i, tacc[i]);
 #endif
+    if (td || tc) {
+        // close the runs still open in registers
+        if (q.tail - q.head > SCQ_CAP - 128) scq_pace(q, gt1, lane, td, tc, 16, false);
+        seq_push(q, seq_nonzero(seq.aA), seq.kA, seq.aA, seq_nonzero(seq.aB), seq.kB, seq.aB);
+    }
     if (td || tc) scq_pace(q, gt1, lane, td, tc, 1 << 20, true);
 
     // ---- flush this wave's weight gradients -------------------------------------------------------
-#ifdef NSR_ABL_NO_MLP
-    if (false) {
-#else
     if (b.grad_mlp) {
-#endif
         float *gm = b.grad_mlp;
         field_wgrad_flush<1, 4>(gm + P_R3, 64, 0, 3, w_r3, lane);
         field_wgrad_flush<4, 4>(gm + P_R2, 64, 0, 64, w_r2, lane);
@@ -724,11 +678,6 @@ int nsr_field_backward(const nsr_field_desc *desc, const void *tables, const flo
     if (feats && ((uintptr_t)feats & 15u)) return NSR_ERR_INVALID_ARG;
     b.grad_sigmas = grad_sigmas; b.grad_rgbs = grad_rgbs; b.grad_tables = grad_tables; b.grad_mlp = grad_mlp;
     b.train_density = train_density_table; b.train_color = train_color_table; b.nc = desc->num_classes;
-    b.fast_levels = 0;
-    for (uint32_t l = 0; l < desc->L; l++) {
-        const NsrLevel &v = b.f.lv[l];
-        if (v.use_hash && v.size && (v.size & (v.size - 1)) == 0) b.fast_levels |= 1u << l;
-    }
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid(nblocks), block(BWD_THREADS);
 #ifdef NSR_ABL_STATS
