@@ -124,6 +124,17 @@ class LossScaler:
     def get_scale(self):
         return self.scale_value
 
+    def state_dict(self):
+        """torch.cuda.amp.GradScaler.state_dict's keys (trainers/base.py:28, SD_SAVE_KEYS 'scaler')"""
+        return {'scale': float(self.scale_value), 'growth_factor': self.growth_factor, 'backoff_factor': self.backoff_factor,
+                'growth_interval': self.growth_interval, '_growth_tracker': int(self._good_steps)}
+
+    def load_state_dict(self, sd):
+        self.scale_value = float(sd['scale'])
+        self.growth_factor, self.backoff_factor = sd['growth_factor'], sd['backoff_factor']
+        self.growth_interval = sd['growth_interval']
+        self._good_steps = int(sd.get('_growth_tracker', 0))
+
     def step(self, opt: FusedAdam) -> bool:
         if not self.enabled:
             opt.step()
