@@ -225,6 +225,7 @@ __device__ __forceinline__ void scq_pace(ScatterQueue &q, float *__restrict__ gt
 // level, so every finished run is emitted exactly once; anything else closes both runs.  Per sample step
 // ~180 instructions for 128 corner touches (the first version of this kernel, a DPP segmented scan over the 16
 // samples of a level with a hashed "row still in the ring" table, needed ~4000 per tile more).
+constexpr int SEQ_K = 4;      // sample steps per ring push
 struct SeqState {
     uint32_t c0, c1, c2;     // cell of the previous sample at this lane's level
     uint32_t kA, kB;         // row + 1 of the open runs (0: none)
@@ -256,16 +257,23 @@ __device__ __forceinline__ bool seq_nonzero(const float4 &v) {
     return ((__float_as_uint(v.x) | __float_as_uint(v.y) | __float_as_uint(v.z) | __float_as_uint(v.w)) << 1) != 0u;
 }
 
-// pushes the (up to two, adjacent) records of every lane
-__device__ __forceinline__ void seq_push(ScatterQueue &q, bool pA, uint32_t kA, const float4 &vA, bool pB, uint32_t kB,
-                                         const float4 &vB) {
-    const unsigned long long mask0 = __ballot(pA), mask1 = __ballot(pB);
-    const int below = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask0, 0u)) +
-                      (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask1, 0u));
-    const int idx0 = q.tail + below, idx1 = idx0 + (pA ? 1 : 0);
-    if (pA) { const int slot = idx0 & SCQ_MASK; q.rows[slot] = kA; q.vals[slot] = vA; }
-    if (pB) { const int slot = idx1 & SCQ_MASK; q.rows[slot] = kB; q.vals[slot] = vB; }
-    q.tail += (int)__popcll(mask0) + (int)__popcll(mask1);
+// pushes the (up to NREC, adjacent) records of every lane, lane-major
+template <int NREC>
+__device__ __forceinline__ void seq_push(ScatterQueue &q, const bool (&p)[NREC], const uint32_t (&k)[NREC], const float4 (&v)[NREC]) {
+    int below = 0, total = 0;
+#pragma unroll
+    for (int r = 0; r < NREC; r++) {
+        const unsigned long long m = __ballot(p[r]);
+        below += (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        total += (int)__popcll(m);
+    }
+    int idx = q.tail + below;
+#pragma unroll
+    for (int r = 0; r < NREC; r++) {
+        if (p[r]) { const int slot = idx & SCQ_MASK; q.rows[slot] = k[r]; q.vals[slot] = v[r]; }
+        idx += p[r] ? 1 : 0;
+    }
+    q.tail += total;
 }
 
 // One tile.  G: this wave's [16 levels][16 samples] float4 staging buffer in LDS; (u0,u1,u2): this lane's
@@ -289,8 +297,16 @@ __device__ __forceinline__ void field_scatter_seq(SeqState &st, const NsrLevel *
     const uint32_t off1 = lv.offset + 1u;
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 gnext = G[l * 16];
-#pragma unroll 2
-    for (int step = 0; step < 16; step++) {
+    // The records of SEQ_K consecutive samples are pushed together, lane-major: a level's records of
+    // neighbouring samples (x-neighbouring rows, often one 64-byte line) then sit next to each other in the ring
+    // and leave in the same atomic instruction (tools/scatter_sim.py: 21.8 -> 19.6 requests/sample for K = 2).
+    bool rp[2 * SEQ_K];
+    uint32_t rk[2 * SEQ_K];
+    float4 rv[2 * SEQ_K];
+    for (int step0 = 0; step0 < 16; step0 += SEQ_K) {
+#pragma unroll
+    for (int sk = 0; sk < SEQ_K; sk++) {
+        const int step = step0 + sk;
         const float4 gr = gnext;
         gnext = G[l * 16 + ((step + 1) & 15)];
         const float su0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, u0), step));
@@ -314,9 +330,8 @@ __device__ __forceinline__ void field_scatter_seq(SeqState &st, const NsrLevel *
         // ---- records that end here ----
         const bool emitA = !same && !sxm && !giveY && !giveZ && seq_nonzero(st.aA);
         const bool emitB = !same && !sxp && !giveY && !giveZ && seq_nonzero(st.aB);
-        if (q.tail - q.head > SCQ_CAP - 128) { NSR_STAT(3, 1); scq_pace(q, gt1, lane, td, tc, 16, false); }
-        seq_push(q, emitA, st.kA, st.aA, emitB, st.kB, st.aB);
-        NSR_STAT(0, __popcll(__ballot(emitA)) + __popcll(__ballot(emitB)));
+        rp[2 * sk] = emitA; rk[2 * sk] = st.kA; rv[2 * sk] = st.aA;
+        rp[2 * sk + 1] = emitB; rk[2 * sk + 1] = st.kB; rv[2 * sk + 1] = st.aB;
         // ---- runs that continue: where from ----
         const float4 nA = seq_quad(st.aA, true), nB = seq_quad(st.aB, true);
         const float4 mA = seq_quad(st.aA, false), mB = seq_quad(st.aB, false);
@@ -339,6 +354,9 @@ __device__ __forceinline__ void field_scatter_seq(SeqState &st, const NsrLevel *
             st.kB = off1 + (iB - qB * lv.size);
             st.c0 = c0; st.c1 = c1; st.c2 = c2;
         }
+    }
+        if (q.tail - q.head > SCQ_CAP - 128 * SEQ_K) { NSR_STAT(3, 1); scq_pace(q, gt1, lane, td, tc, 16 * SEQ_K, false); }
+        seq_push<2 * SEQ_K>(q, rp, rk, rv);
     }
 }
 
@@ -633,7 +651,10 @@ k_field_bwd(FieldBwdArgs b) {
     if (td || tc) {
         // close the runs still open in registers
         if (q.tail - q.head > SCQ_CAP - 128) scq_pace(q, gt1, lane, td, tc, 16, false);
-        seq_push(q, seq_nonzero(seq.aA), seq.kA, seq.aA, seq_nonzero(seq.aB), seq.kB, seq.aB);
+        const bool fp[2] = {seq_nonzero(seq.aA), seq_nonzero(seq.aB)};
+        const uint32_t fk[2] = {seq.kA, seq.kB};
+        const float4 fv[2] = {seq.aA, seq.aB};
+        seq_push<2>(q, fp, fk, fv);
     }
     if (td || tc) scq_pace(q, gt1, lane, td, tc, 1 << 20, true);
 
