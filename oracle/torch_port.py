@@ -127,11 +127,11 @@ class TruncExp(torch.autograd.Function):
 class Field(torch.nn.Module):
     """style_nerf.py:12-142 with use_dir=False, fp32."""
 
-    def __init__(self, num_classes=5, bound=2.0, seed=80000, table_scale=1e-4, sparse_grad=False):
+    def __init__(self, num_classes=5, bound=2.0, seed=80000, table_scale=1e-4, sparse_grad=False, min_res=16):
         super().__init__()
-        self.bound, self.nc, self.sparse_grad = bound, num_classes, sparse_grad
-        self.pls = float(np.exp2(np.log2(1024 * (2 * bound) / 16) / 15))   # tcnn_nerf.py:20-22, bbox size 2*bound
-        self.offsets = grid_offsets(16, self.pls, 16, 19, True)
+        self.bound, self.nc, self.sparse_grad, self.min_res = bound, num_classes, sparse_grad, min_res
+        self.pls = float(np.exp2(np.log2(1024 * (2 * bound) / min_res) / 15))   # tcnn_nerf.py:20-22, bbox size 2*bound
+        self.offsets = grid_offsets(16, self.pls, min_res, 19, True)
         g = torch.Generator().manual_seed(seed)
         R = int(self.offsets[-1])
         self.emb_density = torch.nn.Parameter((torch.rand(R, 2, generator=g) * 2 - 1) * table_scale)
@@ -154,13 +154,13 @@ class Field(torch.nn.Module):
         table_half: gather from f16-rounded tables (the AMP copy)."""
         x = self.encoder_input(pts)
         ed = quant(self.emb_density, 'f16') if table_half else self.emb_density
-        xd = grid_encode(x, ed, self.offsets, self.pls, sparse_grad=self.sparse_grad)
+        xd = grid_encode(x, ed, self.offsets, self.pls, base_resolution=self.min_res, sparse_grad=self.sparse_grad)
         logit = mlp(xd, self.p_density, 32, 1, half=half)
         sigmas = TruncExp.apply(logit)
         if sigma_only:
             return sigmas
         ec = quant(self.emb_color, 'f16') if table_half else self.emb_color
-        xc = grid_encode(x, ec, self.offsets, self.pls, sparse_grad=self.sparse_grad)
+        xc = grid_encode(x, ec, self.offsets, self.pls, base_resolution=self.min_res, sparse_grad=self.sparse_grad)
         classes = mlp(xc, self.p_class, 32, self.nc, half=half)
         c1 = mlp(xc, self.p_color1, 32, 16, half=half)
         rgb = mlp(c1, self.p_color2, 16, 3, n_hidden_layers=2, out_act='sigmoid', half=half)

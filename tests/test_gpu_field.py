@@ -139,14 +139,15 @@ def test_network_forward_backward(O, dev, cfg, dt):
 # ---------------------------------------------------------------------------------------------
 # fused field
 # ---------------------------------------------------------------------------------------------
-def _field_pair(dev, dt, table_dtype, nc=5, table_scale=0.5):
+def _field_pair(dev, dt, table_dtype, nc=5, table_scale=0.5, min_res=16):
     from nerfstyle_amd.common import BBox
-    from nerfstyle_amd.config import NetworkConfig
+    from nerfstyle_amd.config import NetworkConfig, PosEncConfig
     from nerfstyle_amd.style_nerf import StyleTCNerf
     from oracle import torch_port as TP
-    ref = TP.Field(num_classes=nc, table_scale=table_scale)
+    ref = TP.Field(num_classes=nc, table_scale=table_scale, min_res=min_res)
     tdt = torch.float16 if dt == 'f16' else torch.bfloat16
-    m = StyleTCNerf(NetworkConfig(), BBox.from_radius(2.0), nc, enc_dtype=table_dtype, use_dir=False, compute_dtype=tdt)
+    m = StyleTCNerf(NetworkConfig(pos_enc=PosEncConfig(min_res=min_res)), BBox.from_radius(2.0), nc, enc_dtype=table_dtype,
+                    use_dir=False, compute_dtype=tdt)
     sd = m.state_dict()
     sd['x_density_embedder.embeddings'] = ref.emb_density.detach()
     sd['x_color_embedder.embeddings'] = ref.emb_color.detach()
@@ -247,3 +248,63 @@ def test_field_backward(O, dev, dt, table_dtype):
     ((sig * T(gs, dev)).sum() + (rgbs * T(gr, dev)).sum()).backward()
     gt2 = m.arena.grad.cpu().numpy()[:m.table_elems].reshape(m.rows, 2, 2)
     assert np.all(gt2[:, 0, :] == 0) and rel_l2(gt2[:, 1, :], gt[:, 1, :]) < 1e-3
+
+
+@pytest.mark.parametrize('min_res', [16, 2])
+def test_field_backward_run_tracker_on_ray_structured_samples(O, dev, min_res):
+    """The backward's scatter keeps the open run of every (level, corner) in registers along CONSECUTIVE
+    samples and hands runs over when a sample moves one cell along one axis (field_bwd.hip,
+    field_scatter_seq).  Random points never exercise that, so: samples marching along rays with steps from
+    far below a fine cell to several coarse cells, axis-aligned rays in both directions (pure x / y / z
+    hand-overs), samples that stand still, samples outside the box in between (dead lanes), ray ends in
+    the middle of 16-sample tiles.  min_res = 2 makes the coarsest levels dense (use_hash = 0) and not a
+    power of two."""
+    m, ref = _field_pair(dev, 'f16', torch.float32, min_res=min_res)
+    assert int(m.x_density_embedder.offsets[-1]) == int(ref.offsets[-1])
+    rng = np.random.default_rng(7 + min_res)
+    chunks = []
+    for k in range(220):
+        n = int(rng.integers(1, 90))
+        o = (rng.random(3) * 3.6 - 1.8).astype(np.float32)
+        kind = k % 5
+        if kind == 0:                                     # generic direction, march-like step
+            d = rng.standard_normal(3).astype(np.float32)
+            d /= np.linalg.norm(d)
+            step = 2 * np.sqrt(3) / 1024
+        elif kind in (1, 2, 3):                           # axis-aligned, both signs
+            d = np.zeros(3, np.float32)
+            d[kind - 1] = 1.0 if (k // 5) % 2 == 0 else -1.0
+            step = float(rng.choice([1e-4, 2e-3, 3e-2]))
+        else:                                             # coarse jumps
+            d = rng.standard_normal(3).astype(np.float32)
+            d /= np.linalg.norm(d)
+            step = float(rng.choice([0.05, 0.3]))
+        t = np.arange(n, dtype=np.float32)[:, None] * np.float32(step)
+        p = o[None, :] + t * d[None, :]
+        if k % 7 == 0:
+            p[n // 2:] = p[n // 2]                        # the ray stops: repeated identical samples
+        if k % 11 == 0:
+            p[::3] += 10.0                                # every third sample far outside the box (dead)
+        chunks.append(p.astype(np.float32))
+    pts = np.concatenate(chunks)
+    M = pts.shape[0]
+    assert M % 16 != 0
+    gs = (rng.standard_normal(M) * 1e-2).astype(np.float32)
+    gr = rng.standard_normal((M, 8)).astype(np.float32)
+    gr[rng.random(M) < 0.2] = 0.0                         # zero upstream gradients on a fifth of the samples
+    gs[rng.random(M) < 0.2] = 0.0
+    sig, rgbs = m.field(T(pts, dev), False)
+    ((sig * T(gs, dev)).sum() + (rgbs * T(gr, dev)).sum()).backward()
+    # the restatement applies the reference's own out-of-range rule (zero features, gridencoder.cu:118-131): the
+    # encoder input is (x_hat + 1) / 2, so points down to -6 on an axis are still encoded, points above +2 are not
+    out_r, sig_r = ref(torch.tensor(pts), half='f16')
+    ((sig_r[:, 0] * torch.tensor(gs)).sum() + (out_r * torch.tensor(gr)).sum()).backward()
+    gt = m.arena.grad.cpu().numpy()[:m.table_elems].reshape(m.rows, 2, 2)
+    assert rel_l2(gt[:, 0, :], ref.emb_density.grad.numpy()) < 5e-3
+    assert rel_l2(gt[:, 1, :], ref.emb_color.grad.numpy()) < 5e-3
+    assert not np.any((gt[:, 0, :] != 0) & (ref.emb_density.grad.numpy() == 0))
+    # per level, so that a hand-over bug on a small (coarse) level cannot hide behind the fine levels' mass
+    off = np.asarray(ref.offsets)
+    for l in range(16):
+        a, b = gt[off[l]:off[l + 1], 1, :], ref.emb_color.grad.numpy()[off[l]:off[l + 1]]
+        assert rel_l2(a, b) < 1e-2, l
