@@ -308,3 +308,26 @@ def test_field_backward_run_tracker_on_ray_structured_samples(O, dev, min_res):
     for l in range(16):
         a, b = gt[off[l]:off[l + 1], 1, :], ref.emb_color.grad.numpy()[off[l]:off[l + 1]]
         assert rel_l2(a, b) < 1e-2, l
+
+
+@pytest.mark.parametrize('nc', [1, 13])
+def test_field_other_class_counts(O, dev, nc):
+    """C_ch = 3 + nc other than the vectorised 8-channel case: 4 channels (nc = 1) and the largest the
+    16-wide class layer holds (nc = 13); forward and backward against the rounding-emulating restatement."""
+    m, ref = _field_pair(dev, 'f16', torch.float32, nc=nc)
+    rng = np.random.default_rng(nc)
+    M = 3001
+    pts = (rng.random((M, 3)) * 4 - 2).astype(np.float32)
+    gs = (rng.standard_normal(M) * 1e-2).astype(np.float32)
+    gr = rng.standard_normal((M, 3 + nc)).astype(np.float32)
+    sig, rgbs = m.field(T(pts, dev), False)
+    ((sig * T(gs, dev)).sum() + (rgbs * T(gr, dev)).sum()).backward()
+    out_r, sig_r = ref(torch.tensor(pts), half='f16')
+    ((sig_r[:, 0] * torch.tensor(gs)).sum() + (out_r * torch.tensor(gr)).sum()).backward()
+    assert rgbs.shape == (M, 3 + nc)
+    assert rel_l2(rgbs.detach().cpu().numpy(), out_r.detach().numpy()) < 2e-3
+    ga = m.arena.grad.cpu().numpy()
+    gt = ga[:m.table_elems].reshape(m.rows, 2, 2)
+    assert rel_l2(gt[:, 0, :], ref.emb_density.grad.numpy()) < 5e-3
+    assert rel_l2(gt[:, 1, :], ref.emb_color.grad.numpy()) < 5e-3
+    assert rel_l2(ga[m.table_elems + 12288:m.table_elems + 15360], ref.p_class.grad.numpy()) < 5e-3
