@@ -225,11 +225,13 @@ def main():
         # --pmc WRITE_SIZE runs of this same command, corrected as MI355X_MICROARCH.md prescribes);
         # scaled by the sample count of this run, null when the profile does not match the configuration
         traffic_per_sample = {}
+        atomic_req_per_sample = None
         try:
             with open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')) as f:
                 pm = json.load(f)
             if args.table_dtype == 'f16' and args.compute_dtype == 'f16':
                 traffic_per_sample = {k[2:]: v['traffic_bytes_per_sample'] for k, v in pm['kernels'].items()}
+                atomic_req_per_sample = pm['kernels'].get('k_field_bwd', {}).get('atomic_requests_per_sample')
         except (OSError, KeyError, ValueError):
             pass
 
@@ -253,6 +255,14 @@ def main():
             extra['mlp_mfma_fwd'] = {'bound': 'mfma', 'kernel': 'k_field_fwd', 'achieved': round(tf, 1), 'peak': 2500.0,
                                      'unit': 'TFLOP/s', 'frac': round(tf / 2500.0, 4),
                                      'note': 'MLP FLOPs of the fused kernel over its whole duration (gather-bound kernel)'}
+        if 'field_bwd' in prof and atomic_req_per_sample:
+            # the resource k_field_bwd actually saturates: memory-side float-atomic requests (TCC_EA0_ATOMIC per sample
+            # from the PMC pass in profiles/) against the chip-wide rate tools/atomic_footprint_bench.hip measures
+            launches, tot_ms, avg_ms = prof['field_bwd']
+            rate = atomic_req_per_sample * samples / max(launches, 1) / (avg_ms * 1e-3) / 1e9
+            extra['atomic_requests_bwd'] = {'bound': 'memory-side atomic unit', 'kernel': 'k_field_bwd', 'achieved': round(rate, 2),
+                                            'peak': 21.06, 'unit': 'G requests/s', 'frac': round(rate / 21.06, 4),
+                                            'requests_per_sample': atomic_req_per_sample}
         result = {
             'metric': 'train Mrays/sec', 'value': round(value, 4), 'unit': 'Mrays/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True,
