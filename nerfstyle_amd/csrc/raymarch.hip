@@ -3,10 +3,13 @@
 // the structure does not: offsets come from a wave64 shuffle scan + one look-up of per-block
 // totals (deterministic, no atomics), the composite backward keeps its running sums in
 // registers (no rgbs_buf round trip), and every entry point takes an explicit stream.
+#include <stdlib.h>
+
 #include "nsr_common.h"
 
 #define RM_BLOCK 256
 #define RM_SQRT3 1.7320508075688772f
+#define NSR_MARCH_WPR_MAX_RAYS 20480u   // batches up to this size march one wave per ray (k_march_wpr)
 
 // ---------------------------------------------------------------------------------------------
 // small device helpers
@@ -322,6 +325,148 @@ k_march_emit(const float *__restrict__ rays_o, const float *__restrict__ rays_d,
             rm_skip(c, t, tt);
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// training march, one WAVE per ray (small batches)
+// ---------------------------------------------------------------------------------------------
+// The thread-per-ray march above is a serial chain of ~200-instruction probes per ray: 0.85 ms for a
+// 4096-ray batch however idle the chip is.  The parameters the reference visits are the ray-independent
+// sequence t_0 = near (+ noise), t_{k+1} = t_k + clamp(t_k * dt_gamma, dt_min, dt_max) -- both branches of
+// the loop (:484-498) advance t by exactly that expression -- and the loop only decides WHICH t_k it
+// probes: after an occupied probe the next one, after an empty probe the first t_j >= tt.  So a wave
+// takes 64 consecutive t_k, all lanes probe speculatively (same rm_probe, same rounding), every empty
+// lane finds its successor j by binary search over the wave's t values, and a scalar walk follows the
+// successor links from the entry point: exactly the probes, in exactly the order, of the serial loop.
+// Lanes the walk visits and finds occupied are the samples.
+
+// per-block totals of counts[] (the tail of k_march_count)
+__global__ void __launch_bounds__(RM_BLOCK)
+k_march_block_sums(const uint32_t *__restrict__ counts, uint32_t N, uint32_t *__restrict__ block_sums) {
+    __shared__ uint32_t wave_sums[RM_BLOCK / 64];
+    const uint32_t n = blockIdx.x * RM_BLOCK + threadIdx.x;
+    uint32_t total;
+    rm_block_exclusive_scan(n < N ? counts[n] : 0u, wave_sums, total);
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
+}
+
+template <bool EMIT>
+__global__ void __launch_bounds__(256)
+k_march_wpr(const float *__restrict__ rays_o, const float *__restrict__ rays_d, const uint8_t *__restrict__ grid, float bound,
+            float dt_gamma, uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M, const float *__restrict__ nears,
+            const float *__restrict__ fars, const float *__restrict__ noises, uint32_t *__restrict__ counts,
+            const uint32_t *__restrict__ block_bases, float *__restrict__ xyzs, float *__restrict__ dirs,
+            float *__restrict__ deltas, int32_t *__restrict__ rays) {
+    __shared__ float t_lds[4][64];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t n = blockIdx.x * 4 + wave;
+    if (n >= N) return;                                     // wave-uniform
+    float *tl = t_lds[wave];
+    const RmCfg c = rm_cfg(bound, dt_gamma, max_steps, C, H, grid);
+    const RmRay r = rm_load_ray(rays_o, rays_d, n);
+    const float far = fars[n];
+    float t_block = nears[n];
+    {
+#pragma clang fp contract(off)
+        const float noise = noises ? noises[n] : 0.0f;
+        t_block += rm_clamp(t_block * dt_gamma, c.dt_min, c.dt_max) * noise;   // :452
+    }
+    uint32_t limit = max_steps, point_index = 0;
+    if (EMIT) {
+        // offsets: base of this ray's 256-ray block + the counts of the rays before it in the block
+        const uint32_t blk0 = (n / RM_BLOCK) * RM_BLOCK;
+        uint32_t part = 0;
+        for (uint32_t i = blk0 + lane; i < n; i += 64) part += counts[i];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) part += __shfl_xor(part, off, 64);
+        point_index = block_bases[n / RM_BLOCK] + part;
+        limit = counts[n];
+        if (lane == 0) {
+            rays[n * 3 + 0] = (int32_t)n;
+            rays[n * 3 + 1] = (int32_t)point_index;
+            rays[n * 3 + 2] = (int32_t)limit;
+        }
+        if (limit == 0 || point_index + limit >= M) return;   // :517
+    }
+    uint32_t steps = 0;
+    float carry_tt = -INFINITY;       // the walk enters a block at its first t >= carry_tt
+    float last_t = t_block;           // :530, t after the previous sample's step
+    bool done = false;
+    while (!done && t_block < far) {
+        // ---- the block's 64 parameters: every lane runs the serial recurrence and keeps its own ----
+        float my_t = t_block, tc = t_block;
+        {
+#pragma clang fp contract(off)
+            for (uint32_t j = 0; j < 64; j++) {
+                if (lane == j) my_t = tc;
+                tc += rm_clamp(tc * dt_gamma, c.dt_min, c.dt_max);
+            }
+        }
+        const float t_next_block = tc;
+        // ---- speculative probe ----
+        const bool valid = my_t < far;
+        float x = 0, y = 0, z = 0, dt = 0, tt = 0;
+        const bool occ = valid && rm_probe(r, c, valid ? my_t : t_block, x, y, z, dt, tt);
+        // ---- successor of an empty lane: first j > lane with t_j >= tt (do { t += dt; } while (t < tt), :497) ----
+        tl[lane] = my_t;
+        __builtin_amdgcn_wave_barrier();
+        uint32_t lo = lane + 1, hi = 64;
+#pragma unroll
+        for (int it = 0; it < 6; it++) {
+            const uint32_t mid = (lo + hi) >> 1;
+            const float tm = tl[mid < 64 ? mid : 63];
+            const bool go = lo < hi && tm < tt;
+            const bool stay = lo < hi && !(tm < tt);
+            lo = go ? mid + 1 : lo;
+            hi = stay ? mid : hi;
+        }
+        const uint32_t nxt = occ ? lane + 1 : lo;
+        // ---- walk the chain ----
+        const unsigned long long occ_mask = __ballot(occ), valid_mask = __ballot(valid);
+        uint32_t cur = 0;
+        if (carry_tt != -INFINITY) {
+            const unsigned long long ge = __ballot(my_t >= carry_tt);
+            cur = ge ? (uint32_t)__builtin_ctzll(ge) : 64u;
+        }
+        unsigned long long sample_mask = 0ull;
+        uint32_t last = 64;
+        while (cur < 64) {
+            if (!((valid_mask >> cur) & 1ull)) { done = true; break; }          // t >= far
+            if ((occ_mask >> cur) & 1ull) {
+                sample_mask |= 1ull << cur;
+                steps++;
+                if (steps == limit) { done = true; break; }
+            }
+            last = cur;
+            cur = (uint32_t)__builtin_amdgcn_readlane((int)nxt, (int)cur);
+        }
+        if (!done && last < 64)
+            carry_tt = ((occ_mask >> last) & 1ull) ? -INFINITY : __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, tt), (int)last));
+        // ---- emit this block's samples ----
+        if (EMIT && sample_mask) {
+#pragma clang fp contract(off)
+            const bool mine = (sample_mask >> lane) & 1ull;
+            const uint32_t before = (uint32_t)__popcll(sample_mask & ((1ull << lane) - 1ull));
+            const uint32_t first_idx = steps - (uint32_t)__popcll(sample_mask);       // samples emitted before this block
+            const float t_after = my_t + dt;                                            // t += dt, :551
+            __builtin_amdgcn_wave_barrier();
+            tl[lane] = t_after;
+            __builtin_amdgcn_wave_barrier();
+            // t after the previous sample's step: previous sample lane of this block, or the carried one
+            const unsigned long long below = sample_mask & ((1ull << lane) - 1ull);
+            const float prev_t = below ? tl[63 - __builtin_clzll(below)] : last_t;
+            if (mine) {
+                const size_t o = (size_t)point_index + first_idx + before;
+                xyzs[o * 3 + 0] = x; xyzs[o * 3 + 1] = y; xyzs[o * 3 + 2] = z;
+                if (dirs) { dirs[o * 3 + 0] = r.dx; dirs[o * 3 + 1] = r.dy; dirs[o * 3 + 2] = r.dz; }
+                reinterpret_cast<float2 *>(deltas + o * 4)[0] = make_float2(dt, t_after - prev_t);
+            }
+            last_t = tl[63 - __builtin_clzll(sample_mask)];
+        }
+        __builtin_amdgcn_wave_barrier();
+        t_block = t_next_block;
+    }
+    if (!EMIT && lane == 0) counts[n] = steps;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -747,6 +892,20 @@ int nsr_march_rays_train(const float *rays_o, const float *rays_d, const float *
     const uint32_t nblocks = (N + RM_BLOCK - 1) / RM_BLOCK;
     uint32_t *counts = (uint32_t *)workspace;
     uint32_t *block_sums = counts + N;
+    // small batches: one wave per ray (k_march_wpr), bit-identical results; NSR_MARCH_WPR=0/1 forces a path
+    static const int wpr_env = [] { const char *e = getenv("NSR_MARCH_WPR"); return e ? atoi(e) : -1; }();
+    const bool wpr = !is_ndc && (wpr_env >= 0 ? wpr_env != 0 : N <= NSR_MARCH_WPR_MAX_RAYS);
+    if (wpr) {
+        const uint32_t wblocks = (N + 3) / 4;
+        hipLaunchKernelGGL((k_march_wpr<false>), dim3(wblocks), dim3(256), 0, s, rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C,
+                           H, M, nears, fars, noises, counts, (const uint32_t *)nullptr, (float *)nullptr, (float *)nullptr,
+                           (float *)nullptr, (int32_t *)nullptr);
+        hipLaunchKernelGGL(k_march_block_sums, dim3(nblocks), dim3(RM_BLOCK), 0, s, counts, N, block_sums);
+        hipLaunchKernelGGL(k_scan_block_sums, dim3(1), dim3(1024), 0, s, block_sums, nblocks, counter, N);
+        hipLaunchKernelGGL((k_march_wpr<true>), dim3(wblocks), dim3(256), 0, s, rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C,
+                           H, M, nears, fars, noises, counts, block_sums, xyzs, dirs, deltas, rays);
+        return nsr_launch_status();
+    }
     hipLaunchKernelGGL(k_march_count, dim3(nblocks), dim3(RM_BLOCK), 0, s, rays_o, rays_d, grid, bound, dt_gamma, max_steps, N,
                        C, H, nears, fars, noises, counts, block_sums);
     // the reference's ray slots start at the incoming counter[1]; only 0 is supported without a

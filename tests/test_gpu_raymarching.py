@@ -39,16 +39,20 @@ def test_near_far_morton_packbits(O, dev):
     assert R.morton3D(torch.zeros(0, 3, dtype=torch.int32, device=dev)).numel() == 0
 
 
-@pytest.mark.parametrize('n_rays,max_steps', [(4096, 1024), (1000, 512), (257, 64)])
-def test_march_rays_train_bit_exact(O, dev, n_rays, max_steps):
+@pytest.mark.parametrize('n_rays,max_steps,dt_gamma', [(4096, 1024, 0.), (1000, 512, 0.), (257, 64, 0.), (24001, 1024, 0.),
+                                                       (3001, 1024, 1. / 128), (22001, 1024, 1. / 256)])
+def test_march_rays_train_bit_exact(O, dev, n_rays, max_steps, dt_gamma):
+    """Both march implementations against the sequential oracle, bit for bit: batches up to 20 480 rays run
+    one wave per ray (k_march_wpr: speculative probes + successor walk), larger ones one thread per ray;
+    dt_gamma != 0 makes the step grow along the ray (cone marching, raymarching.cu:468)."""
     from nerfstyle_amd import raymarching as R
     grid, bits = small_scene()
     ro, rd = room_rays(O, n_rays, seed=n_rays)
     near, far = O.near_far_from_aabb(ro, rd, AABB, 0.2)
-    xo, do, dlo, rays_o, cnt_o = O.march_rays_train(ro, rd, 2.0, bits, 2, 128, near, far, max_steps, align=128)
+    xo, do, dlo, rays_o, cnt_o = O.march_rays_train(ro, rd, 2.0, bits, 2, 128, near, far, max_steps, dt_gamma=dt_gamma, align=128)
     counter = torch.zeros(2, dtype=torch.int32, device=dev)
     x, d, dl, rays = R.march_rays_train(T(ro, dev), T(rd, dev), None, 2.0, T(bits, dev), 2, 128, T(near, dev), T(far, dev),
-                                        counter, -1, False, 128, True, 0., max_steps, False)
+                                        counter, -1, False, 128, True, dt_gamma, max_steps, False)
     assert np.array_equal(counter.cpu().numpy(), cnt_o)
     assert np.array_equal(rays.cpu().numpy(), rays_o)           # deterministic scan order == sequential oracle order
     assert x.shape == xo.shape
