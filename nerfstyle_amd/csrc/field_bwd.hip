@@ -130,6 +130,9 @@ __device__ __forceinline__ void field_mask_pack(const f4v (&gacc)[4], const s8v 
 //      (SCQ_PACE): atomics are fire-and-forget, but a burst of ~45 back-to-back wave-instructions blocks
 //      at issue once the memory side is saturated, and with one wave per SIMD a blocked wave is an idle
 //      SIMD; and nothing may wait on vmcnt while fresh atomics are in flight (see the loop comment).
+// Ablation builds (never shipped; tools/abl/ + NSR_LIB_PATH): -DNSR_ABL_NO_ATOMIC drops the
+// global atomics (everything else runs), -DNSR_ABL_NO_SCATTER the whole scatter, -DNSR_ABL_STATS adds per-phase
+// s_memtime sums (+ -DNSR_ABL_COUNTS: record / forced-drain counters) printed after every launch.
 #ifdef NSR_ABL_STATS
 __device__ unsigned long long g_stats[8];
 #define NSR_STAT_ALWAYS(i, n) do { if (lane == 0) atomicAdd(&g_stats[i], (unsigned long long)(n)); } while (0)
@@ -141,18 +144,8 @@ __device__ unsigned long long g_stats[8];
 #else
 #define NSR_STAT(i, n) do { } while (0)
 #endif
-#ifdef NSR_ABL_PRIV_ROWS
-#ifndef NSR_ABL_PRIV_COPIES
-#define NSR_ABL_PRIV_COPIES 8
-#endif
-__device__ float g_priv[NSR_ABL_PRIV_COPIES][(NSR_ABL_PRIV_ROWS + 8) * 4];
-#endif
 constexpr int SCQ_CAP = 1024;    // records per wave (power of two)
 constexpr int SCQ_MASK = SCQ_CAP - 1;
-#ifndef NSR_SCQ_KEEP
-#define NSR_SCQ_KEEP 0
-#endif
-constexpr int SCQ_KEEP = NSR_SCQ_KEEP;     // records the paced drain leaves in the ring (experiments only)
 struct ScatterQueue {
     uint32_t *rows;              // [SCQ_CAP]
     float4 *vals;                // [SCQ_CAP]
@@ -176,10 +169,7 @@ __device__ __forceinline__ void scq_drain(ScatterQueue &q, float *__restrict__ g
     if (on) {
 #pragma unroll
         for (int k = 0; k < N; k++) {
-#ifdef NSR_ABL_PRIV_ROWS
-            if (row[k] <= NSR_ABL_PRIV_ROWS) atomicAdd(&g_priv[blockIdx.x % NSR_ABL_PRIV_COPIES][row[k] * 4 + i], v[k]);
-            else atomicAdd(gt1 + (size_t)row[k] * 4 + i, v[k]);
-#elif !defined(NSR_ABL_NO_ATOMIC)
+#ifndef NSR_ABL_NO_ATOMIC
             atomicAdd(gt1 + (size_t)row[k] * 4 + i, v[k]);
 #else
             if (row[k] == 0xFFFFFFFFu) gt1[i] = v[k];
@@ -191,13 +181,11 @@ __device__ __forceinline__ void scq_drain(ScatterQueue &q, float *__restrict__ g
 
 // Issues up to `max_instr` atomic wave-instructions of 16 records.  Only full groups unless `flush`.
 __device__ __forceinline__ void scq_pace(ScatterQueue &q, float *__restrict__ gt1, int lane, bool td, bool tc, int max_instr,
-                                         bool flush, int keep = 0) {
+                                         bool flush) {
     __builtin_amdgcn_wave_barrier();
     const int t = lane >> 2, i = lane & 3;
     const bool on = (i < 2) ? td : tc;
-    // `keep` newest records stay in the ring (paced drains only): the next tile's scatter can still merge
-    // into them through the dedupe table
-    int full = (q.tail - q.head - keep) >> 4;
+    int full = (q.tail - q.head) >> 4;
     if (full > max_instr) full = max_instr;
     NSR_STAT(2, full);
     for (; full >= 4; full -= 4) scq_drain<4>(q, gt1, t, i, on);
@@ -490,7 +478,7 @@ k_field_bwd(FieldBwdArgs b) {
         if (!a.feats) field_encode<TT, CD, false>(lds_lv, tables, u0, u1, u2, live, g, cur.xd, cur.xc);
 
         // paced drain of the previous tile's records: SCQ_PACE(n) issues <= n atomic wave-instructions
-#define SCQ_PACE(n) scq_pace(q, gt1, lane, td, tc, (n), false, SCQ_KEEP)
+#define SCQ_PACE(n) scq_pace(q, gt1, lane, td, tc, (n), false)
         // ================= recompute forward, keeping rounded activations ====================
         s8v xd[1] = {cur.xd}, xc[1] = {cur.xc};
         f4v h[4];
