@@ -163,7 +163,10 @@ def main():
 
     def loss_fn(out, pix):
         mse = torch.mean((out['rgb_map'] - target_rgb[pix]) ** 2)
-        ce = torch.nn.functional.cross_entropy(out['classes'], target_cls[pix]) * 1e-3
+        # cross entropy (trainers/base.py:281, nn.CrossEntropyLoss) as logsumexp - picked logit: same value and
+        # gradient, without torch's one-block nll_loss reduction kernels (0.9 ms per 762 048-ray step)
+        logits = out['classes']
+        ce = (torch.logsumexp(logits, dim=1) - logits.gather(1, target_cls[pix][:, None])[:, 0]).mean() * 1e-3
         return (mse + ce) * (loss_scale / world)
 
     graphed = None
