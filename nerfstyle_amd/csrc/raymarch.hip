@@ -68,7 +68,7 @@ struct RmRay {
     float ox, oy, oz, dx, dy, dz, rdx, rdy, rdz;
 };
 struct RmCfg {
-    float bound, dt_gamma, dt_min, dt_max, rH, H3, Hf, Cf;
+    float bound, rbound, dt_gamma, dt_min, dt_max, rH, H3, Hf, halfH, Cf;
     uint32_t H;
     const uint8_t *grid;
 };
@@ -77,6 +77,8 @@ __device__ __forceinline__ RmCfg rm_cfg(float bound, float dt_gamma, uint32_t ma
                                         const uint8_t *grid) {
     RmCfg c;
     c.bound = bound;
+    c.rbound = 1 / bound;
+    c.halfH = 0.5f * (float)H;
     c.dt_gamma = dt_gamma;
     c.dt_min = 2 * RM_SQRT3 / (float)max_steps;               // :446
     c.dt_max = 2 * RM_SQRT3 * (float)(1 << (C - 1)) / (float)H;  // :447
@@ -105,14 +107,19 @@ __device__ __forceinline__ bool rm_probe(const RmRay &r, const RmCfg &c, float t
     z = rm_clamp(r.oz + t * r.dz, -c.bound, c.bound);
     dt = rm_clamp(t * c.dt_gamma, c.dt_min, c.dt_max);
     const int m1 = rm_mip(fmaxf(fabsf(x), fmaxf(fabsf(y), fabsf(z))), c.Cf);   // :42-47
-    const int m2 = rm_mip((float)((double)(dt * c.Hf) * 0.5), c.Cf);             // :49-54
+    const int m2 = rm_mip((dt * c.Hf) * 0.5f, c.Cf);                             // :49-54 (x 0.5 is exact in either width)
     const int level = max(m1, m2);
-    const float mip_bound = fminf(scalbnf(1.0f, level), c.bound);
-    const float mip_rbound = 1 / mip_bound;
-    // :475-477 -- double product, narrowed by clamp(), truncated
-    const int nx = (int)rm_clamp((float)(0.5 * (double)(x * mip_rbound + 1) * (double)c.H), 0.0f, (float)(c.H - 1));
-    const int ny = (int)rm_clamp((float)(0.5 * (double)(y * mip_rbound + 1) * (double)c.H), 0.0f, (float)(c.H - 1));
-    const int nz = (int)rm_clamp((float)(0.5 * (double)(z * mip_rbound + 1) * (double)c.H), 0.0f, (float)(c.H - 1));
+    const float mip_pow = scalbnf(1.0f, level);
+    const float mip_bound = fminf(mip_pow, c.bound);
+    // 1 / mip_bound (:474): the reciprocal of a power of two is exact, the other case is the loop-invariant
+    // 1 / bound -- the same correctly rounded quotients as the division, without a division per probe
+    const float mip_rbound = mip_pow < c.bound ? scalbnf(1.0f, -level) : c.rbound;
+    // :475-477 computes 0.5 * (double)v * (double)H and narrows once.  v has 24 significant bits, H at most 11:
+    // the double product is exact, so the single rounding of the float product v * (0.5f * H) gives the same
+    // float (0.5f * H is exact too) -- no fp64 in the probe
+    const int nx = (int)rm_clamp((x * mip_rbound + 1) * c.halfH, 0.0f, (float)(c.H - 1));
+    const int ny = (int)rm_clamp((y * mip_rbound + 1) * c.halfH, 0.0f, (float)(c.H - 1));
+    const int nz = (int)rm_clamp((z * mip_rbound + 1) * c.halfH, 0.0f, (float)(c.H - 1));
     const uint32_t index = (uint32_t)((float)level * c.H3 + (float)rm_morton3d(nx, ny, nz));   // :479
     const bool occ = c.grid[index / 8] & (1 << (index % 8));
     if (!occ) {
