@@ -19,10 +19,13 @@ __device__ __forceinline__ float rm_sign(float x) { return copysignf(1.0f, x); }
 
 // raymarching.cu:56-81
 __device__ __forceinline__ uint32_t rm_expand_bits(uint32_t v) {
-    v = (v * 0x00010001u) & 0xFF0000FFu;
-    v = (v * 0x00000101u) & 0x0F00F00Fu;
-    v = (v * 0x00000011u) & 0xC30C30C3u;
-    v = (v * 0x00000005u) & 0x49249249u;
+    // the reference's four multiply-and-mask steps (v * 0x00010001u & 0xFF0000FFu, ...): each product is
+    // v + (v << s) with no overlapping bits after the previous mask, i.e. v | (v << s) -- shift-or runs at full
+    // rate, 32-bit integer multiplies at a quarter of it
+    v = (v | (v << 16)) & 0xFF0000FFu;
+    v = (v | (v << 8)) & 0x0F00F00Fu;
+    v = (v | (v << 4)) & 0xC30C30C3u;
+    v = (v | (v << 2)) & 0x49249249u;
     return v;
 }
 __device__ __forceinline__ uint32_t rm_morton3d(uint32_t x, uint32_t y, uint32_t z) {
