@@ -137,7 +137,17 @@ __device__ __forceinline__ bool rm_probe(const RmRay &r, const RmCfg &c, float t
 
 __device__ __forceinline__ void rm_skip(const RmCfg &c, float &t, float tt) {
 #pragma clang fp contract(off)
-    do { t += rm_clamp(t * c.dt_gamma, c.dt_min, c.dt_max); } while (t < tt);
+    // do { t += clamp(t * dt_gamma, dt_min, dt_max); } while (t < tt);  (:497) -- the same additions in the same
+    // order, four per trip: the first partial sum that is not below tt is the loop's result
+    for (;;) {
+        const float t1 = t + rm_clamp(t * c.dt_gamma, c.dt_min, c.dt_max);
+        const float t2 = t1 + rm_clamp(t1 * c.dt_gamma, c.dt_min, c.dt_max);
+        const float t3 = t2 + rm_clamp(t2 * c.dt_gamma, c.dt_min, c.dt_max);
+        const float t4 = t3 + rm_clamp(t3 * c.dt_gamma, c.dt_min, c.dt_max);
+        const bool b1 = t1 < tt, b2 = t2 < tt, b3 = t3 < tt, b4 = t4 < tt;
+        t = !b1 ? t1 : (!b2 ? t2 : (!b3 ? t3 : t4));
+        if (!(b1 && b2 && b3 && b4)) break;
+    }
 }
 
 __device__ __forceinline__ RmRay rm_load_ray(const float *rays_o, const float *rays_d, uint32_t n) {
