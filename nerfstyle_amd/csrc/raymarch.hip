@@ -523,17 +523,25 @@ k_composite_train_fwd(const float *__restrict__ sigmas, const float *__restrict_
         // RM_CU steps per trip: their loads are issued together (indices clamped into the ray, so the
         // speculation past an early stop stays in bounds) -- the recurrence on T is serial, the memory
         // latency in front of it need not be paid once per step
+        // ... and the NEXT trip's loads are in flight while this trip is evaluated (a wave spent 86 % of its
+        // cycles waiting with one trip at a time)
         bool stop = false;
-        for (uint32_t base = 0; base < num_steps && !stop; base += RM_CU) {
-            float sv[RM_CU], cv[RM_CU];
-            float2 dv[RM_CU];
+        float sv[RM_CU], cv[RM_CU];
+        float2 dv[RM_CU];
+        auto load_trip = [&](uint32_t base, float (&a)[RM_CU], float (&b)[RM_CU], float2 (&e)[RM_CU]) {
 #pragma unroll
             for (uint32_t u = 0; u < RM_CU; u++) {
                 const uint32_t st = min(base + u, num_steps - 1);
-                dv[u] = is_ndc ? *reinterpret_cast<const float2 *>(dl + st * 4 + 2) : *reinterpret_cast<const float2 *>(dl + st * 4);
-                sv[u] = s[st];
-                cv[u] = rgb[(size_t)st * C];
+                e[u] = is_ndc ? *reinterpret_cast<const float2 *>(dl + st * 4 + 2) : *reinterpret_cast<const float2 *>(dl + st * 4);
+                a[u] = s[st];
+                b[u] = rgb[(size_t)st * C];
             }
+        };
+        load_trip(0, sv, cv, dv);
+        for (uint32_t base = 0; base < num_steps && !stop; base += RM_CU) {
+            float nsv[RM_CU], ncv[RM_CU];
+            float2 ndv[RM_CU];
+            load_trip(base + RM_CU, nsv, ncv, ndv);
 #pragma unroll
             for (uint32_t u = 0; u < RM_CU; u++) {
                 if (base + u >= num_steps) { stop = true; break; }
@@ -546,6 +554,8 @@ k_composite_train_fwd(const float *__restrict__ sigmas, const float *__restrict_
                 T *= 1.0f - alpha;
                 if (T < T_thresh) { stop = true; break; }   // :862
             }
+#pragma unroll
+            for (uint32_t u = 0; u < RM_CU; u++) { sv[u] = nsv[u]; cv[u] = ncv[u]; dv[u] = ndv[u]; }
         }
     }
     if (ch == 0) {
@@ -596,15 +606,20 @@ k_composite_train_bwd(const float *__restrict__ grad_weights_sum, const float *_
     // cross-lane sum uses DPP-free shuffles restricted to the group, executed by every live group
     uint32_t step = 0;
     bool stop = false;
-    for (uint32_t base = 0; base < steps && !stop; base += RM_CU) {
-        float sv[RM_CU], cv[RM_CU], dlv[RM_CU];
+    float sv[RM_CU], cv[RM_CU], dlv[RM_CU];
+    auto load_trip = [&](uint32_t base, float (&a)[RM_CU], float (&b)[RM_CU], float (&e)[RM_CU]) {
 #pragma unroll
         for (uint32_t u = 0; u < RM_CU; u++) {
-            const uint32_t st = min(base + u, steps - 1);
-            dlv[u] = is_ndc ? dl[st * 4 + 2] : dl[st * 4 + 0];
-            sv[u] = s[st];
-            cv[u] = has_ch ? rgb[(size_t)st * C] : 0.0f;
+            const uint32_t st = min(base + u, steps ? steps - 1 : 0u);
+            e[u] = steps ? (is_ndc ? dl[st * 4 + 2] : dl[st * 4 + 0]) : 0.0f;
+            a[u] = steps ? s[st] : 0.0f;
+            b[u] = (has_ch && steps) ? rgb[(size_t)st * C] : 0.0f;
         }
+    };
+    load_trip(0, sv, cv, dlv);
+    for (uint32_t base = 0; base < steps && !stop; base += RM_CU) {
+        float nsv[RM_CU], ncv[RM_CU], ndlv[RM_CU];
+        load_trip(base + RM_CU, nsv, ncv, ndlv);          // the next trip's loads fly during this trip
 #pragma unroll
         for (uint32_t u = 0; u < RM_CU; u++) {
             if (base + u >= steps) { stop = true; break; }
@@ -622,6 +637,8 @@ k_composite_train_bwd(const float *__restrict__ grad_weights_sum, const float *_
             if (ch == 0) gs[step] = delta * (gsum + gws * (1 - ws_final));
             step++;
         }
+#pragma unroll
+        for (uint32_t u = 0; u < RM_CU; u++) { sv[u] = nsv[u]; cv[u] = ncv[u]; dlv[u] = ndlv[u]; }
     }
     // samples at and after the early stop keep the zero gradient the reference pre-fills
     if (zero_fill) {
