@@ -44,7 +44,7 @@ k_field_fwd(FieldArgs a) {
         // gridencoder.cu:107-132: inputs outside [0,1] encode to zeros
         const bool live = valid && !(u0 < 0 || u0 > 1 || u1 < 0 || u1 > 1 || u2 < 0 || u2 > 1);
         s8v xd, xc;
-        field_encode<TT, CD, SIGMA_ONLY>(lds_lv, tables, u0, u1, u2, live, g, xd, xc);
+        field_encode<TT, CD, SIGMA_ONLY>(lds_lv, tables, u0, u1, u2, live, g, xd, xc, a.fast_levels);
         if (!SIGMA_ONLY && a.feats) {
             s8v *fo = reinterpret_cast<s8v *>(a.feats) + ((size_t)tile * 64 + lane) * 2;
             fo[0] = xd;

@@ -475,7 +475,7 @@ k_field_bwd(FieldBwdArgs b) {
         for (int e = 0; e < 4; e++)
             cur_grgb[e] = (valid && (a.C_ch == 8 ? g < 2 : (uint32_t)(4 * g + e) < a.C_ch)) ? cur.grgb[e] : 0.f;
         // no saved features: gather them now (dependent loads, the slow path)
-        if (!a.feats) field_encode<TT, CD, false>(lds_lv, tables, u0, u1, u2, live, g, cur.xd, cur.xc);
+        if (!a.feats) field_encode<TT, CD, false>(lds_lv, tables, u0, u1, u2, live, g, cur.xd, cur.xc, a.fast_levels);
 
         // paced drain of the previous tile's records: SCQ_PACE(n) issues <= n atomic wave-instructions
 #define SCQ_PACE(n) scq_pace(q, gt1, lane, td, tc, (n), false)

@@ -36,6 +36,7 @@ struct FieldArgs {
     float density_scale;
     uint32_t C_ch;
     uint32_t tiles_per_block;
+    uint32_t fast_levels;     // bit l: level l is hashed and its size is a power of two
     NsrLevel lv[16];
 };
 
@@ -86,9 +87,13 @@ template <> struct RowLd<_Float16> {
 
 // Trilinear interpolation of one level for both encoders (gridencoder.cu:134-181, align_corners
 // = True, style = 0 on this path: networks/tcnn_nerf.py:26-35).
-template <typename TT, bool SIGMA_ONLY>
+template <typename TT, bool SIGMA_ONLY, bool FAST>
 __device__ __forceinline__ float4 field_encode_level(const NsrLevel &lv, const TT *__restrict__ tables, float u0, float u1,
                                                      float u2, bool live) {
+    // FAST (wave-uniform, from the host's level table): the four levels this call handles, one per 16-lane
+    // group, are all hashed with a power-of-two size, so row = (x ^ y*P1 ^ z*P2) & (size - 1) -- the value
+    // nsr_grid_row gives -- without the per-lane hash/dense select and the invariant-divisor modulo.  Either
+    // way the y and z products are formed once per level, not once per corner.
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     if (live) {
         float f[3];
@@ -96,19 +101,26 @@ __device__ __forceinline__ float4 field_encode_level(const NsrLevel &lv, const T
         nsr_grid_locate(u0, lv.resolution, 1, f[0], c[0]);
         nsr_grid_locate(u1, lv.resolution, 1, f[1], c[1]);
         nsr_grid_locate(u2, lv.resolution, 1, f[2], c[2]);
+        // (wx*wy)*wz: the reference's product order (gridencoder.cu:160-175)
+        const float wxy[4] = {(1 - f[0]) * (1 - f[1]), f[0] * (1 - f[1]), (1 - f[0]) * f[1], f[0] * f[1]};
+        const float wz[2] = {1 - f[2], f[2]};
+        const bool hashed = FAST || lv.use_hash != 0;
+        const uint32_t mulY = hashed ? 2654435761u : lv.mul[1], mulZ = hashed ? 805459861u : lv.mul[2];
+        const uint32_t ty[2] = {c[1] * mulY, (c[1] + 1u) * mulY}, tz[2] = {c[2] * mulZ, (c[2] + 1u) * mulZ};
         uint32_t rows[8];
         float w[8];
 #pragma unroll
         for (uint32_t idx = 0; idx < 8; idx++) {
-            float ww = 1;
-            uint32_t p[3];
-#pragma unroll
-            for (uint32_t d = 0; d < 3; d++) {
-                if ((idx & (1u << d)) == 0) { ww *= 1 - f[d]; p[d] = c[d]; }
-                else { ww *= f[d]; p[d] = c[d] + 1; }
+            w[idx] = wxy[idx & 3] * wz[idx >> 2];
+            const uint32_t x = c[0] + (idx & 1u), a = ty[(idx >> 1) & 1], b = tz[idx >> 2];
+            if (FAST) {
+                rows[idx] = lv.offset + ((x ^ a ^ b) & (lv.size - 1u));
+            } else {
+                const uint32_t index = hashed ? (x ^ a ^ b) : (x * lv.mul[0] + a + b);
+                const uint32_t t = __umulhi(lv.magic, index);
+                const uint32_t q = (t + ((index - t) >> lv.sh1)) >> lv.sh2;
+                rows[idx] = lv.offset + (index - q * lv.size);
             }
-            w[idx] = ww;
-            rows[idx] = lv.offset + nsr_grid_row(lv, p[0], p[1], p[2], 0u);
         }
         if (SIGMA_ONLY) {
             float2 v[8];
@@ -133,12 +145,16 @@ __device__ __forceinline__ float4 field_encode_level(const NsrLevel &lv, const T
 // Encodes this lane's four levels; returns the two K=32 B fragments (density, colour).
 template <typename TT, int CD, bool SIGMA_ONLY>
 __device__ __forceinline__ void field_encode(const NsrLevel *lds_lv, const TT *__restrict__ tables, float u0, float u1, float u2,
-                                             bool live, int g, s8v &xd, s8v &xc) {
+                                             bool live, int g, s8v &xd, s8v &xc, uint32_t fast_levels) {
     const int lvl[4] = {2 * g, 2 * g + 1, 8 + 2 * g, 9 + 2 * g};
+    // levels per call (one per lane group): {0,2,4,6} {1,3,5,7} {8,10,12,14} {9,11,13,15}
+    const uint32_t call_levels[4] = {0x0055u, 0x00AAu, 0x5500u, 0xAA00u};
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         const NsrLevel lv = lds_lv[lvl[i]];
-        const float4 a = field_encode_level<TT, SIGMA_ONLY>(lv, tables, u0, u1, u2, live);
+        const float4 a = (fast_levels & call_levels[i]) == call_levels[i]
+                             ? field_encode_level<TT, SIGMA_ONLY, true>(lv, tables, u0, u1, u2, live)
+                             : field_encode_level<TT, SIGMA_ONLY, false>(lv, tables, u0, u1, u2, live);
         xd[2 * i + 0] = MM<CD>::cvt(a.x);
         xd[2 * i + 1] = MM<CD>::cvt(a.y);
         xc[2 * i + 0] = MM<CD>::cvt(a.z);
@@ -164,9 +180,11 @@ static int field_fill_args(const nsr_field_desc *d, FieldArgs &a, uint32_t M, ui
     if (d->offsets == nullptr) return NSR_ERR_INVALID_ARG;
     NsrLevels lv;
     nsr_fill_levels(&lv, d->offsets, 16, d->S, d->H, 0u);
+    a.fast_levels = 0;
     for (int l = 0; l < 16; l++) {
         a.lv[l] = lv.lv[l];
         if (lv.lv[l].size == 0) return NSR_ERR_INVALID_ARG;
+        if (lv.lv[l].use_hash && (lv.lv[l].size & (lv.lv[l].size - 1u)) == 0) a.fast_levels |= 1u << l;
     }
     for (int i = 0; i < 3; i++) { a.bmin[i] = d->bbox_min[i]; a.bsize[i] = d->bbox_size[i]; }
     a.density_scale = d->density_scale;
