@@ -49,6 +49,13 @@ template <> struct MM<NSR_BF16> {
 // accumulator tile -> 4 rounded elements (optionally ReLU first)
 template <int CD, bool RELU>
 __device__ __forceinline__ s4v mm_round4(f4v a) {
+    if (CD == NSR_F16 && RELU) {
+        // round first, then ReLU on the packed halves (v_pk_max_f16: two elements per instruction).  Rounding to
+        // nearest is monotonic and keeps the sign, so max(round(x), 0) == round(max(x, 0)) bit for bit.
+        const h4v h = {(_Float16)a[0], (_Float16)a[1], (_Float16)a[2], (_Float16)a[3]};
+        const h4v z = {(_Float16)0, (_Float16)0, (_Float16)0, (_Float16)0};
+        return __builtin_bit_cast(s4v, __builtin_elementwise_max(h, z));
+    }
     s4v r;
 #pragma unroll
     for (int i = 0; i < 4; i++) r[i] = MM<CD>::cvt(RELU ? fmaxf(a[i], 0.0f) : a[i]);
