@@ -57,7 +57,7 @@ k_field_fwd(FieldArgs a) {
         {
             const s8v b1[1] = {xd};
             mm_layer32<CD, 4, 1>(wl + FW_D1, lane, b1, h);
-            mm_pack64<CD, true>(h, hb);
+            mm_pack64<CD, true, true>(h, hb);
         }
         f4v o[1];
         mm_layer32<CD, 1, 2>(wl + FW_D2, lane, hb, o);
@@ -69,7 +69,7 @@ k_field_fwd(FieldArgs a) {
         {
             const s8v b1[1] = {xc};
             mm_layer32<CD, 4, 1>(wl + FW_K1, lane, b1, h);
-            mm_pack64<CD, true>(h, hb);
+            mm_pack64<CD, true, true>(h, hb);
             mm_layer32<CD, 1, 2>(wl + FW_K2, lane, hb, cls);
         }
         // ---- color1 net: 32 -> 64 -> 16 ----------------------------------------------------
@@ -77,7 +77,7 @@ k_field_fwd(FieldArgs a) {
         {
             const s8v b1[1] = {xc};
             mm_layer32<CD, 4, 1>(wl + FW_C1A, lane, b1, h);
-            mm_pack64<CD, true>(h, hb);
+            mm_pack64<CD, true, true>(h, hb);
             mm_layer32<CD, 1, 2>(wl + FW_C1B, lane, hb, c1);
         }
         // ---- color2 net: 16 -> 64 -> 64 -> 3, sigmoid --------------------------------------
@@ -85,9 +85,9 @@ k_field_fwd(FieldArgs a) {
         {
             const s4v c1b = mm_round4<CD, false>(c1[0]);
             mm_layer16<CD, 4>(wl + FW_R1, lane, c1b, h);
-            mm_pack64<CD, true>(h, hb);
+            mm_pack64<CD, true, true>(h, hb);
             mm_layer32<CD, 4, 2>(wl + FW_R2, lane, hb, h);
-            mm_pack64<CD, true>(h, hb);
+            mm_pack64<CD, true, true>(h, hb);
             mm_layer32<CD, 1, 2>(wl + FW_R3, lane, hb, rgb);
         }
         // ---- cat(rgb, classes): channel ch = 4g + e (style_nerf.py:141) ---------------------

@@ -348,7 +348,9 @@ __device__ __forceinline__ void field_scatter_seq(SeqState &st, const NsrLevel *
     }
 }
 
-template <typename TT, int CD>
+// FEATS: the forward saved the encoder outputs (the default).  Compile-time because the re-gather path, though
+// never executed then, costs the one-wave-per-SIMD kernel registers and schedule (measured 20.1 vs 20.4-22 ms).
+template <typename TT, int CD, bool FEATS>
 __global__ void __launch_bounds__(BWD_THREADS)
 k_field_bwd(FieldBwdArgs b) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -433,7 +435,7 @@ k_field_bwd(FieldBwdArgs b) {
 #pragma unroll
             for (int e = 0; e < 4; e++) r.grgb[e] = gp[(uint32_t)(4 * g + e) < a.C_ch ? 4 * g + e : 0];
         }
-        if (a.feats) {
+        if (FEATS) {
             // the forward saved this lane's two B fragments: two 16-byte loads instead of 32 gathers
             const s8v *fi = reinterpret_cast<const s8v *>(a.feats) + ((size_t)tile * 64 + lane) * 2;
             r.xd = fi[0];
@@ -475,7 +477,7 @@ k_field_bwd(FieldBwdArgs b) {
         for (int e = 0; e < 4; e++)
             cur_grgb[e] = (valid && (a.C_ch == 8 ? g < 2 : (uint32_t)(4 * g + e) < a.C_ch)) ? cur.grgb[e] : 0.f;
         // no saved features: gather them now (dependent loads, the slow path)
-        if (!a.feats) field_encode<TT, CD, false>(lds_lv, tables, u0, u1, u2, live, g, cur.xd, cur.xc, a.fast_levels);
+        if (!FEATS) field_encode<TT, CD, false>(lds_lv, tables, u0, u1, u2, live, g, cur.xd, cur.xc, a.fast_levels);
 
         // paced drain of the previous tile's records: SCQ_PACE(n) issues <= n atomic wave-instructions
 #define SCQ_PACE(n) scq_pace(q, gt1, lane, td, tc, (n), false)
@@ -701,7 +703,7 @@ int nsr_field_backward(const nsr_field_desc *desc, const void *tables, const flo
 #else
 #define NSR_ABL_REPORT() do { } while (0)
 #endif
-#define NSR_BWD_LAUNCH(TT, CD)                                                                                \
+#define NSR_BWD_LAUNCH(TT, CD, FEATS)                                                                                \
     do {                                                                                                       \
         /* once per process and instantiation (idempotent, so a race is harmless): keeps the call free of   */ \
         /* non-stream API calls, e.g. while the caller captures a hipGraph                                   */ \
@@ -709,19 +711,24 @@ int nsr_field_backward(const nsr_field_desc *desc, const void *tables, const flo
         int dev_ = 0;                                                                                          \
         (void)hipGetDevice(&dev_);                                                                             \
         if (!lds_attr_set[dev_ & 63]) {                                                                                 \
-            if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_field_bwd<TT, CD>),                      \
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_field_bwd<TT, CD, FEATS>),                    \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)BWD_LDS_BYTES) != hipSuccess) \
                 return NSR_ERR_LAUNCH;                                                                         \
             lds_attr_set[dev_ & 63] = true;                                                                            \
         }                                                                                                      \
-        hipLaunchKernelGGL((k_field_bwd<TT, CD>), grid, block, BWD_LDS_BYTES, s, b);                           \
+        hipLaunchKernelGGL((k_field_bwd<TT, CD, FEATS>), grid, block, BWD_LDS_BYTES, s, b);                  \
         NSR_ABL_REPORT();                                                                                      \
         return nsr_launch_status();                                                                            \
     } while (0)
-    if (desc->table_dtype == NSR_F32 && desc->compute_dtype == NSR_F16) NSR_BWD_LAUNCH(float, NSR_F16);
-    if (desc->table_dtype == NSR_F32 && desc->compute_dtype == NSR_BF16) NSR_BWD_LAUNCH(float, NSR_BF16);
-    if (desc->table_dtype == NSR_F16 && desc->compute_dtype == NSR_F16) NSR_BWD_LAUNCH(_Float16, NSR_F16);
-    if (desc->table_dtype == NSR_F16 && desc->compute_dtype == NSR_BF16) NSR_BWD_LAUNCH(_Float16, NSR_BF16);
+    if (feats != nullptr) {                      // no gather in the kernel: the table type does not matter
+        if (desc->compute_dtype == NSR_F16) NSR_BWD_LAUNCH(float, NSR_F16, true);
+        if (desc->compute_dtype == NSR_BF16) NSR_BWD_LAUNCH(float, NSR_BF16, true);
+    } else {
+        if (desc->table_dtype == NSR_F32 && desc->compute_dtype == NSR_F16) NSR_BWD_LAUNCH(float, NSR_F16, false);
+        if (desc->table_dtype == NSR_F32 && desc->compute_dtype == NSR_BF16) NSR_BWD_LAUNCH(float, NSR_BF16, false);
+        if (desc->table_dtype == NSR_F16 && desc->compute_dtype == NSR_F16) NSR_BWD_LAUNCH(_Float16, NSR_F16, false);
+        if (desc->table_dtype == NSR_F16 && desc->compute_dtype == NSR_BF16) NSR_BWD_LAUNCH(_Float16, NSR_BF16, false);
+    }
 #undef NSR_BWD_LAUNCH
     return NSR_ERR_UNSUPPORTED;
 }

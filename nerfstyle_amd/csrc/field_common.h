@@ -72,6 +72,17 @@ template <> struct RowLd<float> {
     static __device__ __forceinline__ float2 dens(const float *t, uint32_t row) {
         return reinterpret_cast<const float2 *>(t)[(size_t)row * 2];
     }
+    // acc += sum over the 8 corners of w * row (all gathers issued first)
+    static __device__ __forceinline__ void accumulate(const float *t, const uint32_t (&rows)[8], const float (&w)[8], float4 &acc) {
+        float4 v[8];
+#pragma unroll
+        for (int idx = 0; idx < 8; idx++) v[idx] = full(t, rows[idx]);
+#pragma unroll
+        for (int idx = 0; idx < 8; idx++) {
+            acc.x += w[idx] * v[idx].x; acc.y += w[idx] * v[idx].y;
+            acc.z += w[idx] * v[idx].z; acc.w += w[idx] * v[idx].w;
+        }
+    }
 };
 template <> struct RowLd<_Float16> {
     static __device__ __forceinline__ float4 full(const _Float16 *t, uint32_t row) {
@@ -82,6 +93,21 @@ template <> struct RowLd<_Float16> {
         typedef _Float16 h2v __attribute__((ext_vector_type(2)));
         const h2v v = reinterpret_cast<const h2v *>(t)[(size_t)row * 2];
         return make_float2((float)v[0], (float)v[1]);
+    }
+    // fp32 accumulation straight from the packed halves: v_fma_mix_f32 widens its f16 operand inside the
+    // multiply-add (same value as v_cvt_f32_f16 followed by v_fma_f32: the widening is exact), so the 32
+    // conversions per level disappear from a kernel that is VALU-issue-bound half of the time
+    static __device__ __forceinline__ void accumulate(const _Float16 *t, const uint32_t (&rows)[8], const float (&w)[8], float4 &acc) {
+        uint2 v[8];
+#pragma unroll
+        for (int idx = 0; idx < 8; idx++) v[idx] = reinterpret_cast<const uint2 *>(t)[rows[idx]];
+#pragma unroll
+        for (int idx = 0; idx < 8; idx++) {
+            asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,0]" : "+v"(acc.x) : "v"(w[idx]), "v"(v[idx].x));
+            asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[0,1,0]" : "+v"(acc.y) : "v"(w[idx]), "v"(v[idx].x));
+            asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,0]" : "+v"(acc.z) : "v"(w[idx]), "v"(v[idx].y));
+            asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[0,1,0]" : "+v"(acc.w) : "v"(w[idx]), "v"(v[idx].y));
+        }
     }
 };
 
@@ -129,14 +155,7 @@ __device__ __forceinline__ float4 field_encode_level(const NsrLevel &lv, const T
 #pragma unroll
             for (int idx = 0; idx < 8; idx++) { acc.x += w[idx] * v[idx].x; acc.y += w[idx] * v[idx].y; }
         } else {
-            float4 v[8];
-#pragma unroll
-            for (int idx = 0; idx < 8; idx++) v[idx] = RowLd<TT>::full(tables, rows[idx]);
-#pragma unroll
-            for (int idx = 0; idx < 8; idx++) {
-                acc.x += w[idx] * v[idx].x; acc.y += w[idx] * v[idx].y;
-                acc.z += w[idx] * v[idx].z; acc.w += w[idx] * v[idx].w;
-            }
+            RowLd<TT>::accumulate(tables, rows, w, acc);
         }
     }
     return acc;

@@ -47,11 +47,12 @@ template <> struct MM<NSR_BF16> {
 };
 
 // accumulator tile -> 4 rounded elements (optionally ReLU first)
-template <int CD, bool RELU>
+template <int CD, bool RELU, bool PKMAX = false>
 __device__ __forceinline__ s4v mm_round4(f4v a) {
-    if (CD == NSR_F16 && RELU) {
+    if (CD == NSR_F16 && RELU && PKMAX) {
         // round first, then ReLU on the packed halves (v_pk_max_f16: two elements per instruction).  Rounding to
-        // nearest is monotonic and keeps the sign, so max(round(x), 0) == round(max(x, 0)) bit for bit.
+        // nearest is monotonic and keeps the sign, so max(round(x), 0) == round(max(x, 0)) bit for bit.  Opt-in:
+        // it pays in the VALU-issue-bound forward kernel, the register-starved backward schedules worse with it.
         const h4v h = {(_Float16)a[0], (_Float16)a[1], (_Float16)a[2], (_Float16)a[3]};
         const h4v z = {(_Float16)0, (_Float16)0, (_Float16)0, (_Float16)0};
         return __builtin_bit_cast(s4v, __builtin_elementwise_max(h, z));
@@ -144,10 +145,10 @@ __device__ __forceinline__ void mm_layer16(const short *lds_frags, int lane, s4v
 }
 
 // 4 accumulator tiles (64 rows) -> two K=32 B fragments, with or without ReLU
-template <int CD, bool RELU>
+template <int CD, bool RELU, bool PKMAX = false>
 __device__ __forceinline__ void mm_pack64(const f4v (&acc)[4], s8v (&out)[2]) {
-    out[0] = mm_cat(mm_round4<CD, RELU>(acc[0]), mm_round4<CD, RELU>(acc[1]));
-    out[1] = mm_cat(mm_round4<CD, RELU>(acc[2]), mm_round4<CD, RELU>(acc[3]));
+    out[0] = mm_cat(mm_round4<CD, RELU, PKMAX>(acc[0]), mm_round4<CD, RELU, PKMAX>(acc[1]));
+    out[1] = mm_cat(mm_round4<CD, RELU, PKMAX>(acc[2]), mm_round4<CD, RELU, PKMAX>(acc[3]));
 }
 
 // Register transpose of a 16x16 block by one MFMA with the identity:
