@@ -74,7 +74,7 @@ class _field(Function):
     is arena.grad) and returns None for it."""
 
     @staticmethod
-    def forward(ctx, xyzs, arena, model, sigma_only, m_dev, density_scale):
+    def forward(ctx, xyzs, arena, model, sigma_only, m_dev, density_scale, want_feats=False):
         xyzs = xyzs.detach().to(torch.float32).contiguous()
         M = xyzs.shape[0]
         dev = xyzs.device
@@ -84,7 +84,8 @@ class _field(Function):
         tables = model._gather_tables()
         # the one thing a training forward saves: the encoded features as MFMA fragments (128 B/sample)
         feats = None
-        if (not sigma_only) and model.save_features and torch.is_grad_enabled() and arena.requires_grad:
+        # (decided by the caller: grad mode is always off inside Function.forward)
+        if (not sigma_only) and want_feats:
             feats = torch.empty(((M + 15) // 16) * 512, dtype=torch.int32, device=dev)
         with profiling.timed('field_fwd_sigma' if sigma_only else 'field_fwd'):
             L.check(L.lib().nsr_field_forward(ctypes.byref(desc), L.p(tables), L.p(model._mlp_flat()),
@@ -121,7 +122,7 @@ class _field(Function):
                 ctypes.byref(desc), L.p(tables), L.p(model._mlp_flat()), L.p(xyzs), M, L.p(ctx.m_dev),
                 L.p(grad_sigmas), L.p(grad_rgbs), L.p(ga), ga.data_ptr() + model.table_elems * 4,
                 int(model.train_density_table), int(model.train_color_table), L.p(ctx.feats), L.stream()), 'field_backward')
-        return None, None, None, None, None, None
+        return None, None, None, None, None, None, None
 
 
 class _EncoderView(nn.Module):
@@ -314,7 +315,8 @@ class StyleTCNerf(nn.Module):
     # ---- forward -------------------------------------------------------------------------------
     def field(self, pts, sigma_only=False, m_dev=None, density_scale=1.0):
         """Fast path: flat sigmas [M] (and rgbs [M,3+nc]); m_dev = device int32 sample count."""
-        return _field.apply(pts, self.arena, self, sigma_only, m_dev, density_scale)
+        want_feats = bool(self.save_features and torch.is_grad_enabled() and self.arena.requires_grad and not sigma_only)
+        return _field.apply(pts, self.arena, self, sigma_only, m_dev, density_scale, want_feats)
 
     def forward(self, pts, dirs=None, bsize=1000000):
         """style_nerf.py:144-159.  The >1M-point chunking of the reference (utils.batch_exec) is
