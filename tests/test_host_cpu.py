@@ -1,5 +1,6 @@
 """Host logic that needs no GPU: sizing, parameter layout, checkpoints, the synthetic scene."""
 import numpy as np
+import pytest
 import torch
 
 from helpers import small_scene
@@ -126,48 +127,26 @@ def test_checkpoint_layout_roundtrip_and_refusal(tmp_path):
         C.load_checkpoint(bad)
 
 
-def test_llff_dataset_loader_and_resident_form(tmp_path):
-    """nerfstyle_amd/dataset.py against a synthetic scene in the torch-ngp LLFF layout the reference reads
-    (data/llff_dataset.py): real room camera JSON fields, random RGBA images, segment maps with -1."""
-    import json
-    from PIL import Image
-    from nerfstyle_amd.dataset import DatasetSplit, LLFFDataset, ResidentDataset
+def test_resident_dataset_targets():
+    """nerfstyle_amd/dataset.py: per-pixel target rows (RGB + segment id) and poses resident on the device,
+    gathered by pixel id -- the rows nerf_lib.generate_rays hands to calc_loss (nerf_lib.py:126-141)."""
+    from nerfstyle_amd.common import Intrinsics
+    from nerfstyle_amd.dataset import ResidentDataset
     from nerfstyle_amd.scene import load_room_cameras
-    poses, intr, meta = load_room_cameras()
+    poses, _, _ = load_room_cameras()
     rng = np.random.default_rng(0)
     h, w, n = 12, 16, 5
-    (tmp_path / 'images').mkdir()
-    (tmp_path / 'seg').mkdir()
-    frames, raw, segs = [], [], []
-    for i in range(n):
-        rgba = rng.integers(0, 256, (h, w, 4), dtype=np.uint8)
-        Image.fromarray(rgba, 'RGBA').save(tmp_path / 'images' / 'f{:02d}.png'.format(i))
-        seg = rng.integers(-1, 3, (h, w)).astype(np.int64)
-        seg.flat[:4] = [-1, 0, 1, 2]
-        np.savez(tmp_path / 'seg' / 'f{:02d}_seg.npz'.format(i), seg_map=seg)
-        T = np.array(meta['poses'][i], np.float64)
-        T[:3, 3] /= 0.33                                   # the asset stores poses with the dataset scale applied
-        frames.append({'file_path': 'images/f{:02d}.png'.format(i), 'transform_matrix': T.tolist()})
-        raw.append(rgba)
-        segs.append(seg)
-    hdr = {'h': h, 'w': w, 'fl_x': 11.5, 'fl_y': 11.5, 'cx': w / 2, 'cy': h / 2}
-    for split in ('train', 'test'):
-        with open(tmp_path / 'transforms_{}.json'.format(split), 'w') as f:
-            json.dump(dict(hdr, frames=frames), f)
-    ds = LLFFDataset(tmp_path, DatasetSplit.TRAIN, scale=0.33, bound=2.0)
-    assert len(ds) == n and ds.num_classes == 3 and ds.intr.w == w and ds.intr.h == h
-    assert np.allclose(ds.poses, poses[:n], atol=1e-6)
-    a = raw[2].astype(np.float32) / 255.0
-    want = a[..., :3] * a[..., 3:] + (1 - a[..., 3:])                       # alpha onto white (base_dataset.py:74-78)
-    img, pose = ds[2]
-    assert img.shape == (4, h, w) and np.allclose(img[:3], want.transpose(2, 0, 1), atol=1e-6)
-    assert np.array_equal(img[3], segs[2].astype(np.float32)) and np.array_equal(pose, ds.poses[2])
-    sub = LLFFDataset(tmp_path, DatasetSplit.TRAIN, max_count=2)
-    assert sub.fns == ['f00', 'f02']                                        # round(linspace(0, 5, 3)[:-1]) = [0, 2]
-    test = LLFFDataset(tmp_path, DatasetSplit.TEST)
-    assert test.images is None and test[1][0] is None and test.fns[0] == 'frame_0'
-    res = ResidentDataset(ds, 'cpu')
+    images = rng.random((n, 3, h, w), dtype=np.float32)
+    segs = rng.integers(-1, 3, (n, h, w))
+    intr = Intrinsics(h, w, 11.5, 11.5, w / 2, h / 2)
+    res = ResidentDataset(images, poses[:n], intr, 2.0, 'cpu', seg_maps=segs, num_classes=3)
+    assert len(res) == n and res.targets.shape == (n, h * w, 4)
     pix = torch.tensor([0, 5, w * h - 1])
     pose_t, tgt = res.sample(2, pix)
-    assert tgt.shape == (3, 4) and torch.equal(pose_t, torch.from_numpy(ds.poses[2]))
-    assert np.allclose(tgt.numpy(), img.reshape(4, -1)[:, pix.numpy()].T)
+    assert tgt.shape == (3, 4) and torch.equal(pose_t, torch.from_numpy(poses[2]))
+    want = np.concatenate((images[2], segs[2][None].astype(np.float32)), 0).reshape(4, -1)[:, pix.numpy()].T
+    assert np.array_equal(tgt.numpy(), want)
+    rgb_only = ResidentDataset(images, poses[:n], intr, 2.0, 'cpu')
+    assert rgb_only.targets.shape == (n, h * w, 3)
+    with pytest.raises(ValueError):
+        ResidentDataset(images[:, :, :-1], poses[:n], intr, 2.0, 'cpu')
