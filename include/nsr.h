@@ -256,6 +256,35 @@ int nsr_adam_step(float *params, float *grads, float *exp_avg, float *exp_avg_sq
                   float grad_scale_inv, float ema_decay, uint32_t step, uint32_t elem_mask4,
                   nsr_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Occupancy-grid update on the device: replaces Renderer.update_state / _compute_occ_sigmas
+ * (renderer.py:120-194), which is torch glue with two host reads (`mean_density.item()`, the size of
+ * `nonzero(density_grid > 0)`).  One update = nsr_occ_sample_points -> nsr_field_forward (sigma only,
+ * rgbs = NULL, on the returned positions) -> nsr_occ_update.  Nothing is read on the host; every call is
+ * capture-safe.  Cells are flat indices cas * H^3 + morton(x, y, z): the layout of density_grid [C, H^3]
+ * (renderer.py:62-63).  H^3 must be a multiple of 256, C <= 8.
+ * ------------------------------------------------------------------------------------------ */
+/* device scratch for both calls (the same buffer must be passed to both calls of one update) */
+uint64_t nsr_occ_workspace_bytes(uint32_t C, uint32_t H);
+/* points of one update: full_update (renderer.py:143-160) C*H^3, one per cell in flat-index order;
+ * else (renderer.py:163-181) per cascade H^3/4 uniform cells followed by H^3/4 draws from the occupied ones */
+uint32_t nsr_occ_num_points(uint32_t C, uint32_t H, int full_update);
+/* xyzs [P,3] f32 = cell centre position 2*c/(H-1)-1 scaled by (b - b/H) plus (u*2-1)*b/H, b = min(2^cas, bound)
+ * (renderer.py:130-133); indices [P] i32 = flat cell index (-1: no point -- the occupied half of a cascade whose
+ * grid is empty, where the reference's randint(0, 0) raises).  u in [0,1): Philox4x32-10 keyed by `seed`, counter =
+ * (point, sequence [+ sequence_dev[0]]) -- the same numbers on every rank; `noise` [P,3] (optional, device)
+ * overrides u (tests pin the jitter with it). */
+int nsr_occ_sample_points(const float *density_grid, uint32_t C, uint32_t H, float bound, int full_update,
+                          uint64_t seed, uint32_t sequence, const uint32_t *sequence_dev, const float *noise,
+                          float *xyzs, int32_t *indices, void *workspace, nsr_stream_t stream);
+/* sigmas [P] f32 = field densities (already x density_scale) at those points.  Applies renderer.py:183-189:
+ * tmp_grid = -1 except tmp_grid[indices] = sigmas; where grid >= 0 and tmp >= 0: grid = max(grid * decay, tmp);
+ * mean_density[0] (device f32) = mean(clamp(grid, 0)); bitfield = packbits(grid, min(mean, density_thresh)).
+ * sequence_dev (optional) is incremented, so a captured graph draws fresh jitter on every replay. */
+int nsr_occ_update(float *density_grid, const float *sigmas, const int32_t *indices, uint32_t P, uint32_t C,
+                   uint32_t H, int full_update, float density_decay, float density_thresh, uint8_t *bitfield,
+                   float *mean_density, uint32_t *sequence_dev, void *workspace, nsr_stream_t stream);
+
 /* Ray generation on the device (nerf_lib.py:69-142 + common.py:139-147): pixel centres
  * (x + 0.5), camera-frame direction ((i-cx)/fx, (j-cy)/fy, 1) * flip, R * d, normalise.
  * pose [4,4] f32 row-major (device).  pix [N] i32 1-D pixel ids (row-major, y * w + x) or NULL

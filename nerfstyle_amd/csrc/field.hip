@@ -42,7 +42,7 @@ k_field_fwd(FieldArgs a) {
             u2 = field_unit(a.xyzs[(size_t)m * 3 + 2], a.bmin[2], a.bsize[2]);
         }
         // gridencoder.cu:107-132: inputs outside [0,1] encode to zeros
-        const bool live = valid && !(u0 < 0 || u0 > 1 || u1 < 0 || u1 > 1 || u2 < 0 || u2 > 1);
+        const bool live = valid && (u0 >= 0 && u0 <= 1 && u1 >= 0 && u1 <= 1 && u2 >= 0 && u2 <= 1);   // NaN -> zeros too
         s8v xd, xc;
         field_encode<TT, CD, SIGMA_ONLY>(lds_lv, tables, u0, u1, u2, live, g, xd, xc, a.fast_levels);
         if (!SIGMA_ONLY && a.feats) {

@@ -6,6 +6,7 @@
 #include <stdlib.h>
 
 #include "nsr_common.h"
+#include "rm_util.h"
 
 #define RM_BLOCK 256
 #define RM_SQRT3 1.7320508075688772f
@@ -16,53 +17,6 @@
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ float rm_clamp(float x, float lo, float hi) { return fminf(hi, fmaxf(lo, x)); }
 __device__ __forceinline__ float rm_sign(float x) { return copysignf(1.0f, x); }
-
-// raymarching.cu:56-81
-__device__ __forceinline__ uint32_t rm_expand_bits(uint32_t v) {
-    // the reference's four multiply-and-mask steps (v * 0x00010001u & 0xFF0000FFu, ...): each product is
-    // v + (v << s) with no overlapping bits after the previous mask, i.e. v | (v << s) -- shift-or runs at full
-    // rate, 32-bit integer multiplies at a quarter of it
-    v = (v | (v << 16)) & 0xFF0000FFu;
-    v = (v | (v << 8)) & 0x0F00F00Fu;
-    v = (v | (v << 4)) & 0xC30C30C3u;
-    v = (v | (v << 2)) & 0x49249249u;
-    return v;
-}
-__device__ __forceinline__ uint32_t rm_morton3d(uint32_t x, uint32_t y, uint32_t z) {
-    return rm_expand_bits(x) | (rm_expand_bits(y) << 1) | (rm_expand_bits(z) << 2);
-}
-__device__ __forceinline__ uint32_t rm_morton3d_invert(uint32_t x) {
-    x = x & 0x49249249;
-    x = (x | (x >> 2)) & 0xc30c30c3;
-    x = (x | (x >> 4)) & 0x0f00f00f;
-    x = (x | (x >> 8)) & 0xff0000ff;
-    x = (x | (x >> 16)) & 0x0000ffff;
-    return x;
-}
-
-// wave64 inclusive scan by shuffles, then a block scan over the (<= 16) wave totals in LDS.
-// Returns the exclusive prefix of v inside the block and the block total in `total`.
-__device__ __forceinline__ uint32_t rm_block_exclusive_scan(uint32_t v, uint32_t *lds_wave_sums, uint32_t &total) {
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    uint32_t incl = v;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t up = __shfl_up(incl, off, 64);
-        if (lane >= (uint32_t)off) incl += up;
-    }
-    if (lane == 63) lds_wave_sums[wave] = incl;
-    __syncthreads();
-    const uint32_t nw = blockDim.x >> 6;
-    uint32_t wave_prefix = 0, tot = 0;
-    for (uint32_t w = 0; w < nw; w++) {
-        const uint32_t s = lds_wave_sums[w];
-        if (w < wave) wave_prefix += s;
-        tot += s;
-    }
-    __syncthreads();
-    total = tot;
-    return wave_prefix + incl - v;
-}
 
 // ---------------------------------------------------------------------------------------------
 // marching core (raymarching.cu:460-500, 530-588, 1059-1119)
@@ -305,7 +259,17 @@ k_march_emit(const float *__restrict__ rays_o, const float *__restrict__ rays_d,
     rays[ray_index * 3 + 1] = (int32_t)point_index;
     rays[ray_index * 3 + 2] = (int32_t)num_steps;
     if (num_steps == 0) return;
-    if (point_index + num_steps >= M) return;   // :517
+    if (point_index + num_steps >= M) {          // :517
+        // dropped ray: the reference's buffers are zero-filled before the launch (raymarching.py:238-240), here they
+        // are torch.empty -- write the in-buffer part, so that no consumer bounded by min(counter[0], M) ever
+        // reads uninitialised positions (a NaN bit pattern would poison the weight gradients as 0 * NaN)
+        for (uint32_t i = point_index; i < min(point_index + num_steps, M); i++) {
+            xyzs[(size_t)i * 3 + 0] = 0.f; xyzs[(size_t)i * 3 + 1] = 0.f; xyzs[(size_t)i * 3 + 2] = 0.f;
+            if (dirs) { dirs[(size_t)i * 3 + 0] = 0.f; dirs[(size_t)i * 3 + 1] = 0.f; dirs[(size_t)i * 3 + 2] = 0.f; }
+            reinterpret_cast<float4 *>(deltas)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        return;
+    }
 
     const RmCfg c = rm_cfg(bound, dt_gamma, max_steps, C, H, grid);
     const RmRay r = rm_load_ray(rays_o, rays_d, n);
@@ -406,7 +370,15 @@ k_march_wpr(const float *__restrict__ rays_o, const float *__restrict__ rays_d, 
             rays[n * 3 + 1] = (int32_t)point_index;
             rays[n * 3 + 2] = (int32_t)limit;
         }
-        if (limit == 0 || point_index + limit >= M) return;   // :517
+        if (limit == 0) return;
+        if (point_index + limit >= M) {          // :517; zero the in-buffer part of a dropped ray (see k_march_emit)
+            for (uint32_t i = point_index + lane; i < min(point_index + limit, M); i += 64) {
+                xyzs[(size_t)i * 3 + 0] = 0.f; xyzs[(size_t)i * 3 + 1] = 0.f; xyzs[(size_t)i * 3 + 2] = 0.f;
+                if (dirs) { dirs[(size_t)i * 3 + 0] = 0.f; dirs[(size_t)i * 3 + 1] = 0.f; dirs[(size_t)i * 3 + 2] = 0.f; }
+                reinterpret_cast<float4 *>(deltas)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            return;
+        }
     }
     uint32_t steps = 0;
     float carry_tt = -INFINITY;       // the walk enters a block at its first t >= carry_tt
@@ -875,7 +847,7 @@ const char *nsr_status_string(int status) {
         default: return "unknown status";
     }
 }
-int nsr_abi_version(void) { return 1; }
+int nsr_abi_version(void) { return 2; }
 const char *nsr_target_arch(void) { return "gfx950"; }
 
 int nsr_near_far_from_aabb(const float *rays_o, const float *rays_d, const float *aabb, uint32_t N, float min_near,

@@ -5,7 +5,8 @@ optimiser step keeps the replicas identical.  The reference has no distributed c
 (device hard-coded to cuda:0, trainers/base.py:119); this is the only collective the path needs.
 
 xGMI is point-to-point (7 links per GPU): a single large message lets RCCL drive all links, so
-the gradient is reduced as one flat bucket (25.2 M fp32 = 100.9 MB; stylisation 50.4 MB), not per
+the gradient is reduced as one flat bucket (25.2 M fp32 = 100.9 MB; stylisation: the packed colour-table
+gradient, 50.4 MB), not per
 tensor.  Loss terms are divided by the world size before backward so the summed gradient equals
 the single-GPU gradient of the global batch.
 """
@@ -19,9 +20,12 @@ def env_world():
     return int(os.environ.get('RANK', 0)), int(os.environ.get('LOCAL_RANK', 0)), int(os.environ.get('WORLD_SIZE', 1))
 
 
-def init(backend=None):
+def init(backend=None, seed=None):
     """Initialises torch.distributed from the torchrun environment (no-op for one process).
-    backend: 'nccl' (= RCCL on ROCm) when CUDA/HIP is available, else 'gloo'."""
+    backend: 'nccl' (= RCCL on ROCm) when CUDA/HIP is available, else 'gloo'.
+    seed: when given, seeds torch's default CPU and device generators IDENTICALLY on every rank, so that anything
+    replicated that still draws from them (parameter init, torch.rand in user loss code) stays identical across
+    ranks.  (The occupancy jitter does not depend on it: Renderer.manual_seed keys a counter-based generator.)"""
     rank, local_rank, world = env_world()
     if world > 1 and not dist.is_initialized():
         if backend is None:
@@ -31,6 +35,8 @@ def init(backend=None):
         if backend == 'nccl' and 'NSR_BENCH_DEVICE' not in os.environ:
             torch.cuda.set_device(local_rank)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    if seed is not None:
+        torch.manual_seed(int(seed))          # seeds the CPU generator and every HIP device generator
     return rank, local_rank, world
 
 
@@ -75,10 +81,21 @@ def broadcast_(flat: torch.Tensor, src=0):
 
 
 def sync_gradients(model, only_color_table=False):
-    """All-reduce of the gradient arena.  Stylisation trains the colour table only
-    (trainers/style.py:25); the interleaved layout keeps both tables in one message either way."""
+    """All-reduce (sum) of the gradient arena: ONE flat 100.9 MB message.
+    only_color_table: the stylisation stage trains `x_color_embedder` alone (trainers/style.py:25).  Its gradient is
+    every second float2 of the interleaved table rows: it is packed into a contiguous 50.4 MB buffer, reduced and
+    unpacked -- half the bytes on the links for two extra streaming passes; the other gradients are left as they are
+    (the optimiser's element mask ignores and zeroes them)."""
     g = model._ensure_grad()
-    return all_reduce_sum_(g)
+    if world_size() == 1:
+        return g
+    if not only_color_table:
+        return all_reduce_sum_(g)
+    colour = g[:model.table_elems].view(model.rows, 2, 2)[:, 1, :]
+    packed = colour.contiguous()
+    all_reduce_sum_(packed)
+    colour.copy_(packed)
+    return g
 
 
 def barrier():

@@ -48,8 +48,10 @@ class Renderer(torch.nn.Module):
         self.density_bitfield = torch.zeros((bitfield_size, ), dtype=torch.uint8)
         self.step_counter = torch.zeros((STEP_CTR_SIZE, 2), dtype=torch.int32)
         self.local_step = 0
-        self.mean_count = 0
-        self.mean_density = 0
+        self._mean_density_dev, self._mean_density_host = None, 0.0
+        self._mean_count_host, self._mean_count_stale = 0, False
+        self._occ_state = None
+        self.occ_seed = 0
         self.device = torch.device('cpu')
 
     # TensorModule behaviour of the reference (common.py:207-240): plain tensor attributes move too
@@ -58,6 +60,8 @@ class Renderer(torch.nn.Module):
             setattr(self, k, fn(getattr(self, k)))
         super()._apply(fn, *args, **kwargs)
         self.device = self.aabb.device
+        if self._mean_density_dev is not None and self._mean_density_dev.device != self.device:
+            self.mean_density = float(self._mean_density_dev.item())
         return self
 
     def state_dict(self):
@@ -92,53 +96,80 @@ class Renderer(torch.nn.Module):
         self._use_precrop = value
 
     # ---- occupancy grid ------------------------------------------------------------------------
-    def _compute_occ_sigmas(self, xyzs, cas):
-        """renderer.py:120-136"""
-        bound = min(2 ** cas, self.bound)
-        half_grid_size = bound / self.cfg.grid_size
-        cas_xyzs = xyzs * (bound - half_grid_size)
-        cas_xyzs += (torch.rand_like(cas_xyzs) * 2 - 1) * half_grid_size
-        return self.model.field(cas_xyzs, sigma_only=True, density_scale=self.cfg.density_scale).detach()
+    @property
+    def mean_density(self) -> float:
+        """renderer.py:186 keeps a host float; here the value lives on the device and is read only when asked for."""
+        if self._mean_density_dev is not None:
+            return float(self._mean_density_dev.item())
+        return self._mean_density_host
+
+    @mean_density.setter
+    def mean_density(self, v):
+        self._mean_density_host = float(v)
+        self._mean_density_dev = None
+
+    @property
+    def mean_count(self) -> int:
+        """renderer.py:192-194 (mean emitted samples of the last min(16, update_iter) steps).  The reference marches
+        with force_all_rays=True (:219-221), so the value is checkpoint state only: computed when read."""
+        if self._mean_count_stale and self.step_counter.is_cuda:
+            total_step = min(STEP_CTR_SIZE, self.cfg.update_iter)
+            self._mean_count_host = int(self.step_counter[:total_step, 0].sum().item() / total_step)
+            self._mean_count_stale = False
+        return self._mean_count_host
+
+    @mean_count.setter
+    def mean_count(self, v):
+        self._mean_count_host = int(v)
+        self._mean_count_stale = False
+
+    def manual_seed(self, seed: int):
+        """Seed of the occupancy jitter / cell draws (counter-based: every rank that uses the same seed draws
+        the same points, so data-parallel replicas keep identical grids without a collective)."""
+        self.occ_seed = int(seed)
+        return self
+
+    def _occ_buffers(self, P):
+        """Scratch of one update; allocated once per shape (no allocation in the steady state)."""
+        key = (P, str(self.device))
+        if getattr(self, '_occ_key', None) != key:
+            from . import _lib as L
+            dev = self.device
+            nbytes = int(L.lib().nsr_occ_workspace_bytes(self.cascade, self.cfg.grid_size))
+            if nbytes == 0:
+                raise RuntimeError('occupancy grid of size {} x {}^3 is not supported (H^3 must be a multiple of 256)'.format(
+                    self.cascade, self.cfg.grid_size))
+            self._occ_ws = torch.empty((nbytes + 3) // 4, dtype=torch.int32, device=dev)
+            self._occ_xyzs = torch.empty(P, 3, dtype=torch.float32, device=dev)
+            self._occ_idx = torch.empty(P, dtype=torch.int32, device=dev)
+            self._occ_key = key
+        return self._occ_ws, self._occ_xyzs, self._occ_idx
 
     @torch.no_grad()
-    def update_state(self) -> None:
-        """renderer.py:139-194"""
-        tmp_grid = -torch.ones_like(self.density_grid)
-        gs = self.cfg.grid_size
-        if self.local_step < self.cfg.update_thres:
-            bsize = self.cfg.grid_bsize or gs
-            splits = [torch.arange(gs, dtype=torch.int32, device=self.device).split(bsize) for _ in range(3)]
-            for xs in splits[0]:
-                for ys in splits[1]:
-                    for zs in splits[2]:
-                        xx, yy, zz = torch.meshgrid(xs, ys, zs, indexing='ij')
-                        coords = torch.cat([xx.reshape(-1, 1), yy.reshape(-1, 1), zz.reshape(-1, 1)], dim=-1)
-                        indices = raymarching.morton3D(coords).long()
-                        xyzs = 2 * coords.float() / (gs - 1) - 1
-                        for cas in range(self.cascade):
-                            tmp_grid[cas, indices] = self._compute_occ_sigmas(xyzs, cas)
-        else:
-            N = gs ** 3 // 4
-            for cas in range(self.cascade):
-                coords = torch.randint(0, gs, (N, 3), device=self.device)
-                indices = raymarching.morton3D(coords).long()
-                occ_indices = torch.nonzero(self.density_grid[cas] > 0).squeeze(-1)
-                rand_mask = torch.randint(0, occ_indices.shape[0], [N], dtype=torch.long, device=self.device)
-                occ_indices = occ_indices[rand_mask]
-                occ_coords = raymarching.morton3D_invert(occ_indices)
-                indices = torch.cat([indices, occ_indices], dim=0)
-                coords = torch.cat([coords, occ_coords], dim=0)
-                xyzs = 2 * coords.float() / (gs - 1) - 1
-                tmp_grid[cas, indices] = self._compute_occ_sigmas(xyzs, cas)
-
-        valid_mask = (self.density_grid >= 0) & (tmp_grid >= 0)
-        self.density_grid[valid_mask] = torch.maximum(
-            self.density_grid[valid_mask] * self.cfg.density_decay, tmp_grid[valid_mask])
-        self.mean_density = torch.mean(self.density_grid.clamp(min=0)).item()
-        density_thresh = min(self.mean_density, self.cfg.density_thresh)
-        self.density_bitfield = raymarching.packbits(self.density_grid, density_thresh, self.density_bitfield)
-        total_step = min(STEP_CTR_SIZE, self.cfg.update_iter)
-        self.mean_count = int(self.step_counter[:total_step, 0].sum().item() / total_step)
+    def update_state(self, noise: Optional[torch.Tensor] = None) -> None:
+        """renderer.py:139-194 on the device: cell choice + jitter (nsr_occ_sample_points), the sigma-only fused
+        field on those points, then scatter / max-decay / mean / packbits (nsr_occ_update).  No host read, no
+        allocation after the first call, legal under hipGraph capture.  `noise` [P,3] in [0,1) pins the jitter."""
+        from . import _lib as L
+        C, H = self.cascade, self.cfg.grid_size
+        full = 1 if self.local_step < self.cfg.update_thres else 0
+        P = int(L.lib().nsr_occ_num_points(C, H, full))
+        ws, xyzs, idx = self._occ_buffers(P)
+        if self._occ_state is None or self._occ_state.device != self.device:
+            self._occ_state = torch.zeros(4, dtype=torch.int32, device=self.device)    # [0]: update sequence
+        if self._mean_density_dev is None:
+            self._mean_density_dev = torch.full((1,), self._mean_density_host, dtype=torch.float32, device=self.device)
+        if not self.density_grid.is_contiguous():
+            self.density_grid = self.density_grid.contiguous()
+        L.check(L.lib().nsr_occ_sample_points(L.p(self.density_grid), C, H, float(self.bound), full, self.occ_seed, 0,
+                                              L.p(self._occ_state), L.p(noise), L.p(xyzs), L.p(idx), L.p(ws), L.stream()),
+                'occ_sample_points')
+        sigmas = self.model.field(xyzs, sigma_only=True, density_scale=self.cfg.density_scale)
+        L.check(L.lib().nsr_occ_update(L.p(self.density_grid), L.p(sigmas), L.p(idx), P, C, H, full,
+                                       float(self.cfg.density_decay), float(self.cfg.density_thresh),
+                                       L.p(self.density_bitfield), L.p(self._mean_density_dev), L.p(self._occ_state),
+                                       L.p(ws), L.stream()), 'occ_update')
+        self._mean_count_stale = True
 
     # ---- training render -----------------------------------------------------------------------
     def sample_capacity(self, n_rays: int) -> int:
@@ -161,6 +192,7 @@ class Renderer(torch.nn.Module):
         self._last_counter = counter     # device-side (samples, rays) of this call; never read here
         N = rays.origins.shape[0]
         M = self.sample_capacity(N)
+        self._last_capacity = M
         xyzs, _, deltas, rays_info = raymarching.march_rays_train_nosync(
             rays.origins, rays.dirs, self.bound, self.density_bitfield, self.cascade, self.cfg.grid_size, nears, fars,
             M, counter, 0., self.cfg.max_steps)
@@ -171,6 +203,12 @@ class Renderer(torch.nn.Module):
         image = image + (1 - weights_sum).unsqueeze(-1)
         depth = torch.clamp(depth - nears, min=0) / (fars - nears)
         return image, depth, classes
+
+    def last_call_overflowed(self) -> torch.Tensor:
+        """Device-side flag (0-dim bool tensor, no host sync) of the last render_train call: the march emitted
+        at least `capacity` samples, so the rays at the end of the batch were dropped exactly like the reference's
+        mean_count path does (raymarching.cu:517).  Their in-buffer samples are zero-filled and carry zero gradient."""
+        return self._last_counter[0] >= self._last_capacity
 
     # ---- inference render ----------------------------------------------------------------------
     @torch.no_grad()
@@ -189,6 +227,13 @@ class Renderer(torch.nn.Module):
         xyzs, _, deltas, rays_info = raymarching.march_rays_train_nosync(
             rays.origins, rays.dirs, self.bound, self.density_bitfield, self.cascade, self.cfg.grid_size, nears, fars,
             M, counter, 0., self.cfg.max_steps)
+        if self.samples_per_ray_cap is not None and self.samples_per_ray_cap < self.cfg.max_steps:
+            # a bounded buffer can overflow, and the march then DROPS the rays that do not fit (raymarching.cu:517);
+            # the reference's inference loop never drops a ray, so fall back to its iteration structure.  One host read
+            # per frame (the reference reads the alive count every iteration); never taken with the default capacity.
+            self.last_test_overflow = int(counter[0].item()) >= M
+            if self.last_test_overflow:
+                return self.render_test_loop(rays, **kwargs)
         sigmas, rgbs = self.model.field(xyzs, sigma_only=False, m_dev=counter, density_scale=self.cfg.density_scale)
         C = self.raymarch_channels
         weights_sum = torch.empty(N, dtype=torch.float32, device=self.device)

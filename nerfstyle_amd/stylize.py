@@ -59,7 +59,7 @@ def _all_gather_ragged(chunks, part):
 
 
 def deferred_backprop_step(renderer, pose, image_loss: Callable[[torch.Tensor], torch.Tensor], patch_size: int = 200,
-                           loss_scale: float = 1.0, rank: int = 0, world: int = 1):
+                           loss_scale: float = 1.0, rank: int = 0, world: int = 1, only_color_table: bool = True):
     """One stylisation iteration up to (not including) the optimiser step.  `image_loss` maps
     rgb [H, W, 3] (requires_grad) to a scalar.  Gradients accumulate into model.arena.grad.
     Returns (loss value, rgb_map of pass 1)."""
@@ -75,5 +75,5 @@ def deferred_backprop_step(renderer, pose, image_loss: Callable[[torch.Tensor], 
         g = grad_map[box.y:box.y + box.h, box.x:box.x + box.w].reshape(-1, 3)
         out['rgb_map'].backward(g)                         # style.py:196-198
     if world > 1:
-        P.sync_gradients(renderer.model)
+        P.sync_gradients(renderer.model, only_color_table=only_color_table)
     return loss.detach(), rgb.detach()

@@ -44,6 +44,23 @@ assert torch.equal(flat2, torch.full((10,), 3.0))
 t = torch.arange(5.) * (rank + 1); P.broadcast_(t, 0)
 assert torch.equal(t, torch.arange(5.))
 assert P.max_over_ranks(float(rank), "cpu") == 1.0
+# colour-table-only reduction on the interleaved rows: [row][enc][feat], enc 1 = colour
+class M:
+    rows, table_elems = 6, 24
+    def __init__(self): self.g = torch.arange(24 + 5, dtype=torch.float32) * (rank + 1)
+    def _ensure_grad(self): return self.g
+m = M(); before = m.g.clone()
+P.sync_gradients(m, only_color_table=True)
+t4 = m.g[:24].view(6, 2, 2); b4 = before[:24].view(6, 2, 2)
+assert torch.equal(t4[:, 1], torch.arange(24.).view(6, 2, 2)[:, 1] * 3)      # summed over ranks 1x + 2x
+assert torch.equal(t4[:, 0], b4[:, 0]) and torch.equal(m.g[24:], before[24:]) # everything else untouched
+m2 = M(); P.sync_gradients(m2)
+assert torch.equal(m2.g, torch.arange(29.) * 3)
+# identical default-generator streams after init(seed=...)
+P.init(backend="gloo", seed=1234)
+r = torch.rand(4); rs = [torch.zeros(4) for _ in range(world)]
+torch.distributed.all_gather(rs, r)
+assert torch.equal(rs[0], rs[1])
 P.barrier()
 print("RANK_OK", rank)
 '''

@@ -1,0 +1,123 @@
+"""GPU: the N > 1 training path rehearsed on ONE card.  Two fresh processes (gloo rendezvous, both on cuda:0) each run 3
+training steps on their half of a fixed pixel set -- occupancy update from the replicated model, render, loss / world,
+backward, all-reduce of the gradient arena, fused Adam -- and a third fresh process runs the same 3 steps on the whole
+set alone.  Replicas must end bit-identical to each other (same reduced gradient, same counter-based occupancy draws) and
+equal to the single-process run up to the fp32 summation order of the table atomics (first-step gradient within
+1e-5 relative L2; parameters after three Adam steps equal except for a < 1e-5 fraction of near-zero-gradient entries).
+
+Child processes are started with subprocess (never a re-exec of a process that has touched the GPU)."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CHILD = r'''
+import os, sys
+sys.path.insert(0, os.environ["NSR_ROOT"])
+import torch
+from nerfstyle_amd import parallel as P
+torch.cuda.set_device(0)
+os.environ["NSR_BENCH_DEVICE"] = "0"
+rank, local_rank, world = P.init(backend="gloo", seed=77)
+dev = torch.device("cuda", 0)
+from nerfstyle_amd.common import BBox
+from nerfstyle_amd.config import NetworkConfig, RendererConfig
+from nerfstyle_amd.optim import FusedAdam
+from nerfstyle_amd.renderer import Renderer
+from nerfstyle_amd.scene import load_room_cameras
+from nerfstyle_amd.style_nerf import StyleTCNerf
+nc = 5
+model = StyleTCNerf(NetworkConfig(), BBox.from_radius(2.0), nc, enc_dtype=None, use_dir=False)
+poses, intr, _ = load_room_cameras()
+r = Renderer(model, RendererConfig.llff(), intr, 2.0, raymarch_channels=3 + nc, samples_per_ray_cap=1024).to(dev).manual_seed(5)
+assert r.update_occ                                     # occupancy from the model itself, every rank draws the same cells
+opt = FusedAdam(model, lr=1e-2, ema_decay=0.95)
+g = torch.Generator().manual_seed(3)
+npix = intr.w * intr.h
+pix_all = torch.randperm(npix, generator=g)[:2048].to(dev)
+target = torch.rand(npix, 3, generator=g).to(dev)
+tcls = torch.randint(0, nc, (npix,), generator=g).to(dev)
+b, e = P.shard_bounds(pix_all.numel(), rank, world)
+pix = pix_all[b:e]
+SCALE = 65536.0
+pose = torch.tensor(poses, device=dev)
+for it in range(3):
+    out = r.render(pose[it], None, training=True, pix_subset=pix)
+    # sums normalised by the GLOBAL ray count: the summed gradient equals the single-process gradient
+    mse = ((out["rgb_map"] - target[pix]) ** 2).sum() / (3 * pix_all.numel())
+    lg = out["classes"]
+    ce = (torch.logsumexp(lg, 1) - lg.gather(1, tcls[pix][:, None])[:, 0]).sum() / pix_all.numel() * 1e-3
+    ((mse + ce) * SCALE).backward()
+    if world > 1:
+        P.sync_gradients(model)
+    if it == 0:
+        grad0 = (model.arena.grad.detach() / SCALE).cpu()
+    opt.step(grad_scale=SCALE)
+torch.cuda.synchronize()
+torch.save({"grad0": grad0, "arena": model.arena.detach().cpu(), "ema": opt.ema.cpu(), "bitfield": r.density_bitfield.cpu(),
+            "grid": r.density_grid.cpu(), "samples": r.step_counter.cpu()}, os.environ["NSR_OUT"])
+P.barrier()
+print("CHILD_OK", rank, world)
+'''
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run(script, world, tmp_path, tag):
+    port = _free_port()
+    procs, outs = [], []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1',
+                   MASTER_PORT=str(port), NSR_ROOT=ROOT, NSR_OUT=str(tmp_path / '{}_{}.pt'.format(tag, rank)), OMP_NUM_THREADS='2')
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                                      text=True))
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=420)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            out, _ = p.communicate()
+        outs.append(out)
+    for rank, (p, out) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, out[-3000:]
+        assert 'CHILD_OK {} {}'.format(rank, world) in out
+    return [torch.load(tmp_path / '{}_{}.pt'.format(tag, rank), weights_only=True) for rank in range(world)]
+
+
+def test_two_ranks_on_one_gpu_keep_identical_replicas(tmp_path):
+    assert torch.cuda.is_available()
+    script = tmp_path / 'child.py'
+    script.write_text(CHILD)
+    two = _run(script, 2, tmp_path, 'w2')
+    one = _run(script, 1, tmp_path, 'w1')[0]
+    a, b = two
+    for k in ('arena', 'ema', 'bitfield', 'grid'):
+        assert torch.equal(a[k], b[k]), k                     # replicas bit-identical
+    assert not torch.equal(a['samples'], b['samples'])         # ... while marching different rays
+    assert int(a['bitfield'].count_nonzero()) > 0
+    assert torch.equal(a['bitfield'], one['bitfield'])         # step-0 occupancy: same weights, same draws
+    # the reduced gradient of the first step equals the single-process gradient up to fp32 summation order
+    rel = float((a['grad0'].double() - one['grad0'].double()).norm() / one['grad0'].double().norm())
+    assert rel < 1e-5, rel
+    assert int(((a['grad0'] == 0) != (one['grad0'] == 0)).sum()) < 10
+    # after three Adam steps: Adam's first steps move a parameter by lr * sign(g), so the handful of entries whose
+    # gradient cancels to ~0 may differ by 2 * lr; everything else agrees to fp32 noise
+    d = (a['arena'] - one['arena']).abs()
+    assert float((d > 1e-5).float().mean()) < 1e-5
+    rel_arena = float(d.double().norm() / one['arena'].double().norm())
+    assert rel_arena < 1e-3, rel_arena
+    moved = float((one['arena'] - one['ema']).abs().max())
+    assert moved > 1e-4                                        # the three steps did train
