@@ -288,7 +288,8 @@ def test_device_occupancy_update_partial_matches_restatement(O, dev):
         centre = _oracle_cell_positions(O, H, cas, ii - cas * H3, np.full((2 * N, 3), 0.5, np.float32))
         half = min(2 ** cas, 2.0) / H
         assert np.abs(xyz_h[lo:lo + 2 * N] - centre).max() <= half * (1 + 1e-4)
-    sig = r.model.field(xyzs, sigma_only=True, density_scale=1.0)
+    with torch.no_grad():
+        sig = r.model.field(xyzs, sigma_only=True, density_scale=1.0)
     L.check(L.lib().nsr_occ_update(L.p(r.density_grid), L.p(sig), L.p(idx), P, 2, H, 0, 0.95, 10.0, L.p(r.density_bitfield),
                                    L.p(r._mean_density_dev), None, L.p(ws), L.stream()))
     after = r.density_grid.cpu().numpy().reshape(-1)
