@@ -224,9 +224,12 @@ typedef struct nsr_field_desc {
  * feats (optional, may be NULL): ceil(M/16)*2048 bytes that receive the encoded features of both
  * encoders as ready-made MFMA B fragments (128 B per sample, the only thing a training forward
  * saves); pass the same buffer to nsr_field_backward to skip its re-gather. */
+/* perm (optional, may be NULL): device uint32 [M] from nsr_sample_order -- the kernel's tile t then works on samples
+ * perm[16t .. 16t+15] of the buffers (outputs land at those samples' own slots; `feats` stays tile-major, so the
+ * backward must be given the same perm).  Results per sample are bit-identical with and without it. */
 int nsr_field_forward(const nsr_field_desc *desc, const void *tables, const float *mlp_params,
                       const float *xyzs, uint32_t M, const int32_t *m_dev, float *sigmas, float *rgbs,
-                      void *feats, nsr_stream_t stream);
+                      void *feats, const uint32_t *perm, nsr_stream_t stream);
 
 /* grad_sigmas [M], grad_rgbs [M,3+nc] f32.  Recomputes the forward (nothing saved), then
  * back-propagates: trunc_exp' = exp(clamp(logit,-15,15)) (tcnn_nerf.py:62-66), sigmoid', ReLU
@@ -238,7 +241,19 @@ int nsr_field_backward(const nsr_field_desc *desc, const void *tables, const flo
                        const float *xyzs, uint32_t M, const int32_t *m_dev, const float *grad_sigmas,
                        const float *grad_rgbs, float *grad_tables, float *grad_mlp,
                        int train_density_table, int train_color_table, const void *feats,
-                       nsr_stream_t stream);
+                       const uint32_t *perm, nsr_stream_t stream);
+
+/* Spatial processing order of marched samples (no reference counterpart; see csrc/sample_order.hip): perm [M] u32 =
+ * indices of the first min(m_dev[0], M) samples in Morton order of their encoder input (10 bits per axis, stable: ray
+ * order inside a 4^3-finest-cell block), followed by the remaining slots.  sort_prefix <= M: how many leading slots
+ * take part in the sort (the emitted count lives on the device; pass an estimate >= it, or M; a smaller value is still
+ * correct -- the slots past it keep identity order).  With perm the fused backward accumulates table gradients in
+ * LDS lattice tiles and issues ~3x fewer atomic requests on dense (full-frame) batches.
+ * workspace: nsr_sample_order_workspace_bytes(M) bytes, 256-byte aligned.  bbox_min / bbox_size: HOST float[3]. */
+uint64_t nsr_sample_order_workspace_bytes(uint32_t M);
+int nsr_sample_order(const float *xyzs, uint32_t M, const int32_t *m_dev, uint32_t sort_prefix,
+                     const float *bbox_min, const float *bbox_size, uint32_t *perm, void *workspace,
+                     nsr_stream_t stream);
 
 /* fp32 master tables -> f16 gather copy (the reference's `embeddings.to(torch.half)` under
  * autocast, grid.py:42-43).  n = number of scalars. */

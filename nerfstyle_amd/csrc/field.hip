@@ -33,8 +33,10 @@ k_field_fwd(FieldArgs a) {
     const uint32_t t_end = min(t_begin + tpb, ntiles);
 
     for (uint32_t tile = t_begin + wave; tile < t_end; tile += 4) {
-        const uint32_t m = tile * 16 + s;
-        const bool valid = m < Mc;
+        const uint32_t mpos = tile * 16 + s;
+        const bool valid = mpos < Mc;
+        // spatially ordered walk (nsr_sample_order): position `mpos` of the order is sample perm[mpos] of the buffers
+        const uint32_t m = (a.perm && valid) ? a.perm[mpos] : mpos;
         float u0 = 0.f, u1 = 0.f, u2 = 0.f;
         if (valid) {
             u0 = field_unit(a.xyzs[(size_t)m * 3 + 0], a.bmin[0], a.bsize[0]);
@@ -128,7 +130,7 @@ static int field_launch_fwd(const FieldArgs &a, uint32_t nblocks, bool sigma_onl
 extern "C" {
 
 int nsr_field_forward(const nsr_field_desc *desc, const void *tables, const float *mlp_params, const float *xyzs, uint32_t M,
-                      const int32_t *m_dev, float *sigmas, float *rgbs, void *feats, nsr_stream_t stream) {
+                      const int32_t *m_dev, float *sigmas, float *rgbs, void *feats, const uint32_t *perm, nsr_stream_t stream) {
     if (M == 0) return NSR_OK;
     NSR_CHECK_PTR(desc); NSR_CHECK_PTR(tables); NSR_CHECK_PTR(mlp_params); NSR_CHECK_PTR(xyzs); NSR_CHECK_PTR(sigmas);
     FieldArgs a;
@@ -139,6 +141,7 @@ int nsr_field_forward(const nsr_field_desc *desc, const void *tables, const floa
     if (rgbs && a.C_ch == 8 && ((uintptr_t)rgbs & 15u)) return NSR_ERR_INVALID_ARG;
     a.tables = tables; a.params = mlp_params; a.xyzs = xyzs; a.m_dev = m_dev; a.sigmas = sigmas; a.rgbs = rgbs;
     a.feats = feats;
+    a.perm = perm;
     if (feats && ((uintptr_t)feats & 15u)) return NSR_ERR_INVALID_ARG;
     const bool so = rgbs == nullptr;
     hipStream_t s = (hipStream_t)stream;

@@ -348,9 +348,144 @@ __device__ __forceinline__ void field_scatter_seq(SeqState &st, const NsrLevel *
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Lattice accumulator (SORTED kernels: samples walked in the spatial order of nsr_sample_order).
+//
+// In Morton order consecutive samples -- of MANY rays -- sit in the same few cells on every level, so the wave keeps,
+// per level, the corner gradients of one aligned TILE of cells in LDS: 4^3 cells (5^3 = 125 corners) on the fine
+// levels, 2^3 cells (27 corners) on the coarse ones, 17 KB per wave.  Lane = (level l = lane >> 2, y/z corner pair
+// p = lane & 3) walks the tile's 16 samples in order and adds its two x corners' contributions with a plain LDS
+// read-modify-write -- no atomics are needed: within a step the 64 lanes touch 128 different lattice slots, and steps
+// are sequential.  No hashing per sample either: the lattice is addressed by cell coordinates; rows are computed only
+// when a level's tile is left and its touched corners are flushed, one merged record per corner (tools/
+// sorted_scatter_sim.py: 11.7 records and 5.9 atomic requests per sample on the bench scene against 29.7 / 19.3 of
+// the ray-order run tracker, at a third of its instructions).  A flush is cooperative: 16 corners per
+// wave-instruction, 4 lanes per corner, so the four dwords of a row leave as ONE 16-byte request and the x-aligned
+// corners of a row group (tile origin is a multiple of 4 cells) share their 64-byte line.
+constexpr int LAT_FINE0 = 10;                        // levels >= LAT_FINE0: 4^3-cell tiles; below: 2^3-cell tiles
+constexpr int LAT_COARSE_SLOTS = 32, LAT_FINE_SLOTS = 128;
+constexpr int LAT_TOTAL = LAT_FINE0 * LAT_COARSE_SLOTS + (16 - LAT_FINE0) * LAT_FINE_SLOTS;   // float4 slots per wave
+constexpr size_t BWD_LAT_BYTES_PER_WAVE = (size_t)LAT_TOTAL * 16 + 16 * 16 * 16;                // lattice + staging
+constexpr size_t BWD_LDS_BYTES_SORTED = (size_t)FW_TOTAL * 2 + (size_t)BW_TOTAL * 2 + 16 * sizeof(NsrLevel) +
+                                        (BWD_THREADS / 64) * BWD_LAT_BYTES_PER_WAVE;
+constexpr uint32_t LAT_NONE = 0xFFFFFFFFu;
+__device__ __forceinline__ int lat_base(int l) {
+    return l < LAT_FINE0 ? l * LAT_COARSE_SLOTS : LAT_FINE0 * LAT_COARSE_SLOTS + (l - LAT_FINE0) * LAT_FINE_SLOTS;
+}
+struct LatState {
+    uint32_t t0, t1, t2;     // tile (cell >> log2 T) this lane's level is accumulating; LAT_NONE: nothing yet
+};
+
+// Flushes level l's tile (t0, t1, t2) -- wave-uniform arguments -- and clears it.
+template <int LOG2T>
+__device__ __forceinline__ void lat_flush_level(float4 *__restrict__ lat, int l, uint32_t t0, uint32_t t1, uint32_t t2,
+                                                const NsrLevel &lv, float *__restrict__ gt, int lane, bool td, bool tc) {
+    constexpr int T = 1 << LOG2T, S = T + 1, NC = S * S * S;
+    float *lf = reinterpret_cast<float *>(lat + lat_base(l));
+    const int t = lane >> 2, i = lane & 3;
+    const bool on = (i < 2) ? td : tc;
+#pragma unroll 1
+    for (int k0 = 0; k0 < NC; k0 += 16) {
+        const int k = k0 + t;
+        float v = 0.0f;
+        if (k < NC) v = lf[k * 4 + i];
+        const unsigned long long nzm = __ballot(v != 0.0f);
+        if ((nzm >> (lane & ~3)) & 0xFull) {                 // any component of this corner is non-zero
+            const int z = k / (S * S), r = k - z * (S * S), y = r / S, x = r - y * S;
+            const uint32_t row = lv.offset + nsr_grid_row(lv, t0 * T + (uint32_t)x, t1 * T + (uint32_t)y, t2 * T + (uint32_t)z, 0u);
+#ifndef NSR_ABL_NO_ATOMIC
+            if (on) atomicAdd(gt + (size_t)row * 4 + i, v);
+#else
+            if (on && row == 0xFFFFFFFFu) gt[i] = v;
+#endif
+            lf[k * 4 + i] = 0.0f;
+        }
+    }
+}
+
+// One tile of 16 (spatially ordered) samples.  G: this wave's [16 levels][16 samples] float4 staging buffer; (u0,u1,u2):
+// this lane's SAMPLE (lane & 15) position; sg[i]: its gradients for level lvl[i]; live: this lane's sample is inside.
+__device__ __forceinline__ void field_scatter_lattice(LatState &st, const NsrLevel *__restrict__ lds_lv, float4 *__restrict__ G,
+                                                      float4 *__restrict__ lat, float *__restrict__ gt, float u0, float u1, float u2,
+                                                      bool live, const float4 (&sg)[4], int lane, bool td, bool tc) {
+#ifdef NSR_ABL_NO_SCATTER
+    if (lane >= 0) return;
+#endif
+    const int s = lane & 15, g = lane >> 4;
+    const int lvl[4] = {2 * g, 2 * g + 1, 8 + 2 * g, 9 + 2 * g};
+#pragma unroll
+    for (int i = 0; i < 4; i++) G[lvl[i] * 16 + s] = sg[i];
+    const uint32_t live16 = (uint32_t)(__ballot(live) & 0xFFFFull);      // lanes 0..15 are samples 0..15
+    __builtin_amdgcn_wave_barrier();
+    const int l = lane >> 2, py = lane & 1, pz = (lane >> 1) & 1;
+    const NsrLevel lv = lds_lv[l];
+    const bool fine = l >= LAT_FINE0;
+    const uint32_t sh = fine ? 2u : 1u, msk = fine ? 3u : 1u, S = fine ? 5u : 3u;
+    float4 *const mylat = lat + lat_base(l) + ((uint32_t)pz * S + (uint32_t)py) * S;
+#pragma unroll
+    for (int step = 0; step < 16; step++) {
+        if (!((live16 >> step) & 1u)) continue;                            // wave-uniform
+        const float4 gr = G[l * 16 + step];
+        const float su0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, u0), step));
+        const float su1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, u1), step));
+        const float su2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, u2), step));
+        float f0, f1, f2;
+        uint32_t c0, c1, c2;
+        nsr_grid_locate(su0, lv.resolution, 1, f0, c0);
+        nsr_grid_locate(su1, lv.resolution, 1, f1, c1);
+        nsr_grid_locate(su2, lv.resolution, 1, f2, c2);
+        const uint32_t n0 = c0 >> sh, n1 = c1 >> sh, n2 = c2 >> sh;
+        const bool chg = (n0 != st.t0) | (n1 != st.t1) | (n2 != st.t2);
+        unsigned long long mm = __ballot(chg);
+        if (mm) {                                                          // some level leaves its tile
+            do {
+                const int fl = (int)(__builtin_ctzll(mm) >> 2);
+                mm &= ~(0xFull << (fl * 4));
+                const uint32_t o0 = (uint32_t)__builtin_amdgcn_readlane((int)st.t0, fl * 4);
+                if (o0 != LAT_NONE) {
+                    const uint32_t o1 = (uint32_t)__builtin_amdgcn_readlane((int)st.t1, fl * 4);
+                    const uint32_t o2 = (uint32_t)__builtin_amdgcn_readlane((int)st.t2, fl * 4);
+                    const NsrLevel flv = lds_lv[fl];
+                    if (fl >= LAT_FINE0) lat_flush_level<2>(lat, fl, o0, o1, o2, flv, gt, lane, td, tc);
+                    else lat_flush_level<1>(lat, fl, o0, o1, o2, flv, gt, lane, td, tc);
+                }
+            } while (mm);
+            if (chg) { st.t0 = n0; st.t1 = n1; st.t2 = n2; }
+        }
+        // this sample's contribution to the lane's two x corners: (wx*wy)*wz, the product order of the forward
+        const float wy = py ? f1 : 1 - f1, wz = pz ? f2 : 1 - f2;
+        const float wA = ((1 - f0) * wy) * wz, wB = (f0 * wy) * wz;
+        float4 *const slot = mylat + (((c2 & msk) * S + (c1 & msk)) * S + (c0 & msk));
+        float4 a = slot[0], b = slot[1];
+        a.x = fmaf(wA, gr.x, a.x); a.y = fmaf(wA, gr.y, a.y); a.z = fmaf(wA, gr.z, a.z); a.w = fmaf(wA, gr.w, a.w);
+        b.x = fmaf(wB, gr.x, b.x); b.y = fmaf(wB, gr.y, b.y); b.z = fmaf(wB, gr.z, b.z); b.w = fmaf(wB, gr.w, b.w);
+        slot[0] = a;
+        slot[1] = b;
+    }
+}
+
+// End of a wave's tile range: every level's open tile leaves.
+__device__ __forceinline__ void field_scatter_lattice_finish(LatState &st, const NsrLevel *__restrict__ lds_lv, float4 *__restrict__ lat,
+                                                             float *__restrict__ gt, int lane, bool td, bool tc) {
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll 1
+    for (int fl = 0; fl < 16; fl++) {
+        const uint32_t o0 = (uint32_t)__builtin_amdgcn_readlane((int)st.t0, fl * 4);
+        if (o0 == LAT_NONE) continue;
+        const uint32_t o1 = (uint32_t)__builtin_amdgcn_readlane((int)st.t1, fl * 4);
+        const uint32_t o2 = (uint32_t)__builtin_amdgcn_readlane((int)st.t2, fl * 4);
+        const NsrLevel flv = lds_lv[fl];
+        if (fl >= LAT_FINE0) lat_flush_level<2>(lat, fl, o0, o1, o2, flv, gt, lane, td, tc);
+        else lat_flush_level<1>(lat, fl, o0, o1, o2, flv, gt, lane, td, tc);
+    }
+    st.t0 = st.t1 = st.t2 = LAT_NONE;
+}
+
 // FEATS: the forward saved the encoder outputs (the default).  Compile-time because the re-gather path, though
 // never executed then, costs the one-wave-per-SIMD kernel registers and schedule (measured 20.1 vs 20.4-22 ms).
-template <typename TT, int CD, bool FEATS>
+// SORTED: the samples are walked through FieldArgs::perm (nsr_sample_order) and scattered by the lattice accumulator;
+// otherwise in buffer (ray) order by the sequential run tracker.
+template <typename TT, int CD, bool FEATS, bool SORTED>
 __global__ void __launch_bounds__(BWD_THREADS)
 k_field_bwd(FieldBwdArgs b) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -376,20 +511,28 @@ k_field_bwd(FieldBwdArgs b) {
     const s4v ident = mm_identity_frag<CD>(lane);
     const int nc = (int)b.nc;
     ScatterQueue q;
+    q.rows = nullptr; q.vals = nullptr; q.head = q.tail = 0;
     char *qbase_g;
-    {
-        char *qbase = smem + (size_t)(FW_TOTAL + BW_TOTAL) * 2 + 16 * sizeof(NsrLevel) +
-                      (size_t)wave * BWD_QUEUE_BYTES_PER_WAVE;
+    float4 *lat = nullptr;
+    char *const wave_lds = smem + (size_t)(FW_TOTAL + BW_TOTAL) * 2 + 16 * sizeof(NsrLevel);
+    if (SORTED) {
+        char *base = wave_lds + (size_t)wave * BWD_LAT_BYTES_PER_WAVE;
+        lat = reinterpret_cast<float4 *>(base);
+        qbase_g = base + (size_t)LAT_TOTAL * 16;
+        for (int k = lane; k < LAT_TOTAL; k += 64) lat[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    } else {
+        char *qbase = wave_lds + (size_t)wave * BWD_QUEUE_BYTES_PER_WAVE;
         q.vals = reinterpret_cast<float4 *>(qbase);
         q.rows = reinterpret_cast<uint32_t *>(qbase + SCQ_CAP * 16);
         qbase_g = qbase + SCQ_CAP * 20;
         for (int k = lane; k < SCQ_CAP; k += 64) q.rows[k] = 0u;        // keys are row + 1: 0 matches nothing
-        q.head = q.tail = 0;
     }
     SeqState seq;
     seq.c0 = seq.c1 = seq.c2 = 0x7FFFFFF0u;
     seq.kA = seq.kB = 0u;
     seq.aA = seq.aB = make_float4(0.f, 0.f, 0.f, 0.f);
+    LatState latst;
+    latst.t0 = latst.t1 = latst.t2 = LAT_NONE;
     float4 *const seqG = reinterpret_cast<float4 *>(qbase_g);        // [16 levels][16 samples] float4 staging, 4 KB
     const bool td = b.train_density != 0, tc = b.train_color != 0;
     float *const gt1 = b.grad_tables - 4;      // ring rows are stored +1 (field_scatter_level)
@@ -419,10 +562,15 @@ k_field_bwd(FieldBwdArgs b) {
         float gsig;        // grad_sigmas[m] (used by the g == 0 lanes)
         float grgb[4];     // grad_rgbs[m, 4g .. 4g+3]
     };
-    auto load_tile = [&](uint32_t tile) {
-        TileIn r;
+    // position `16 * tile + s` of the walk -> index into the sample buffers (0 for lanes past the count)
+    auto fetch_idx = [&](uint32_t tile) -> uint32_t {
         const uint32_t m = tile * 16 + s;
-        const size_t mc = m < Mc ? m : 0u;
+        if (m >= Mc) return 0u;
+        return (SORTED && a.perm) ? a.perm[m] : m;
+    };
+    auto load_tile = [&](uint32_t tile, uint32_t buf_idx) {
+        TileIn r;
+        const size_t mc = buf_idx;
         r.x0 = a.xyzs[mc * 3 + 0];
         r.x1 = a.xyzs[mc * 3 + 1];
         r.x2 = a.xyzs[mc * 3 + 2];
@@ -448,7 +596,13 @@ k_field_bwd(FieldBwdArgs b) {
     const uint32_t wchunk = (t_end > t_begin ? (t_end - t_begin + BWD_THREADS / 64 - 1) / (BWD_THREADS / 64) : 0u);
     const uint32_t w_begin = min(t_begin + wave * wchunk, t_end), w_end = min(w_begin + wchunk, t_end);
     TileIn cur;
-    if (w_begin < w_end) cur = load_tile(w_begin);
+    // SORTED: the permutation entry of a tile is fetched one tile ahead of its data, so that no load in the steady
+    // state depends on a load issued in the same batch
+    uint32_t idx_next = 0;
+    if (w_begin < w_end) {
+        cur = load_tile(w_begin, fetch_idx(w_begin));
+        if (w_begin + 1 < w_end) idx_next = fetch_idx(w_begin + 1);
+    }
 
 #ifdef NSR_ABL_STATS
     unsigned long long tacc[4] = {0, 0, 0, 0};
@@ -480,7 +634,7 @@ k_field_bwd(FieldBwdArgs b) {
         if (!FEATS) field_encode<TT, CD, false>(lds_lv, tables, u0, u1, u2, live, g, cur.xd, cur.xc, a.fast_levels);
 
         // paced drain of the previous tile's records: SCQ_PACE(n) issues <= n atomic wave-instructions
-#define SCQ_PACE(n) scq_pace(q, gt1, lane, td, tc, (n), false)
+#define SCQ_PACE(n) do { if (!SORTED) scq_pace(q, gt1, lane, td, tc, (n), false); } while (0)
         // ================= recompute forward, keeping rounded activations ====================
         s8v xd[1] = {cur.xd}, xc[1] = {cur.xc};
         f4v h[4];
@@ -619,7 +773,7 @@ k_field_bwd(FieldBwdArgs b) {
         // turned into atomics by the pace points of the next tile), so by the next loop top both these loads
         // and the atomics issued ahead of them (vmcnt retires in order) have had the whole scatter to land.
         TileIn nxt = cur;
-        if (tile + 1 < w_end) nxt = load_tile(tile + 1);
+        if (!SORTED && tile + 1 < w_end) nxt = load_tile(tile + 1, fetch_idx(tile + 1));
         NSR_TICK(tk3);
         NSR_TACC(3, tk2, tk3);
         if (td || tc) {
@@ -629,7 +783,14 @@ k_field_bwd(FieldBwdArgs b) {
                 const int t = i >> 1, e0 = 2 * (i & 1);
                 sg[i] = live ? make_float4(gxd[t][e0], gxd[t][e0 + 1], gxc[t][e0], gxc[t][e0 + 1]) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
-            field_scatter_seq(seq, lds_lv, seqG, q, gt1, live ? u0 : 0.f, live ? u1 : 0.f, live ? u2 : 0.f, sg, lane, td, tc);
+            if (SORTED) field_scatter_lattice(latst, lds_lv, seqG, lat, b.grad_tables, u0, u1, u2, live, sg, lane, td, tc);
+            else field_scatter_seq(seq, lds_lv, seqG, q, gt1, live ? u0 : 0.f, live ? u1 : 0.f, live ? u2 : 0.f, sg, lane, td, tc);
+        }
+        if (SORTED && tile + 1 < w_end) {
+            // the lattice flushes issue their atomics inline, so the next tile's loads go out AFTER the scatter: a load
+            // issued before it could only be waited for together with every atomic behind it (one in-order vmcnt)
+            nxt = load_tile(tile + 1, idx_next);
+            if (tile + 2 < w_end) idx_next = fetch_idx(tile + 2);
         }
         NSR_TICK(tk4);
         NSR_TACC(2, tk3, tk4);
@@ -638,15 +799,17 @@ k_field_bwd(FieldBwdArgs b) {
 #ifdef NSR_ABL_STATS
     for (int i = 0; i < 4; i++) NSR_STAT_ALWAYS(4 + i, tacc[i]);
 #endif
-    if (td || tc) {
+    if (SORTED) {
+        if (td || tc) field_scatter_lattice_finish(latst, lds_lv, lat, b.grad_tables, lane, td, tc);
+    } else if (td || tc) {
         // close the runs still open in registers
         if (q.tail - q.head > SCQ_CAP - 128) scq_pace(q, gt1, lane, td, tc, 16, false);
         const bool fp[2] = {seq_nonzero(seq.aA), seq_nonzero(seq.aB)};
         const uint32_t fk[2] = {seq.kA, seq.kB};
         const float4 fv[2] = {seq.aA, seq.aB};
         seq_push<2>(q, fp, fk, fv);
+        scq_pace(q, gt1, lane, td, tc, 1 << 20, true);
     }
-    if (td || tc) scq_pace(q, gt1, lane, td, tc, 1 << 20, true);
 
     // ---- flush this wave's weight gradients -------------------------------------------------------
     if (b.grad_mlp) {
@@ -668,7 +831,7 @@ extern "C" {
 int nsr_field_backward(const nsr_field_desc *desc, const void *tables, const float *mlp_params, const float *xyzs, uint32_t M,
                        const int32_t *m_dev, const float *grad_sigmas, const float *grad_rgbs, float *grad_tables,
                        float *grad_mlp, int train_density_table, int train_color_table, const void *feats,
-                       nsr_stream_t stream) {
+                       const uint32_t *perm, nsr_stream_t stream) {
     if (M == 0) return NSR_OK;
     NSR_CHECK_PTR(desc); NSR_CHECK_PTR(tables); NSR_CHECK_PTR(mlp_params); NSR_CHECK_PTR(xyzs);
     NSR_CHECK_PTR(grad_sigmas); NSR_CHECK_PTR(grad_rgbs);
@@ -686,6 +849,7 @@ int nsr_field_backward(const nsr_field_desc *desc, const void *tables, const flo
     b.f.tiles_per_block = (ntiles + nblocks - 1) / nblocks;
     b.f.tables = tables; b.f.params = mlp_params; b.f.xyzs = xyzs; b.f.m_dev = m_dev; b.f.sigmas = nullptr; b.f.rgbs = nullptr;
     b.f.feats = const_cast<void *>(feats);
+    b.f.perm = perm;
     if (feats && ((uintptr_t)feats & 15u)) return NSR_ERR_INVALID_ARG;
     b.grad_sigmas = grad_sigmas; b.grad_rgbs = grad_rgbs; b.grad_tables = grad_tables; b.grad_mlp = grad_mlp;
     b.train_density = train_density_table; b.train_color = train_color_table; b.nc = desc->num_classes;
@@ -703,22 +867,27 @@ int nsr_field_backward(const nsr_field_desc *desc, const void *tables, const flo
 #else
 #define NSR_ABL_REPORT() do { } while (0)
 #endif
-#define NSR_BWD_LAUNCH(TT, CD, FEATS)                                                                                \
+#define NSR_BWD_LAUNCH_(TT, CD, FEATS, SORTED, LDSB)                                                              \
     do {                                                                                                       \
         /* once per process and instantiation (idempotent, so a race is harmless): keeps the call free of   */ \
         /* non-stream API calls, e.g. while the caller captures a hipGraph                                   */ \
         static bool lds_attr_set[64] = {};                                                                     \
         int dev_ = 0;                                                                                          \
         (void)hipGetDevice(&dev_);                                                                             \
-        if (!lds_attr_set[dev_ & 63]) {                                                                                 \
-            if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_field_bwd<TT, CD, FEATS>),                    \
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)BWD_LDS_BYTES) != hipSuccess) \
+        if (!lds_attr_set[dev_ & 63]) {                                                                        \
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_field_bwd<TT, CD, FEATS, SORTED>),       \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDSB)) != hipSuccess)    \
                 return NSR_ERR_LAUNCH;                                                                         \
-            lds_attr_set[dev_ & 63] = true;                                                                            \
+            lds_attr_set[dev_ & 63] = true;                                                                    \
         }                                                                                                      \
-        hipLaunchKernelGGL((k_field_bwd<TT, CD, FEATS>), grid, block, BWD_LDS_BYTES, s, b);                  \
+        hipLaunchKernelGGL((k_field_bwd<TT, CD, FEATS, SORTED>), grid, block, (LDSB), s, b);                   \
         NSR_ABL_REPORT();                                                                                      \
         return nsr_launch_status();                                                                            \
+    } while (0)
+#define NSR_BWD_LAUNCH(TT, CD, FEATS)                                                                          \
+    do {                                                                                                       \
+        if (perm != nullptr) NSR_BWD_LAUNCH_(TT, CD, FEATS, true, BWD_LDS_BYTES_SORTED);                       \
+        NSR_BWD_LAUNCH_(TT, CD, FEATS, false, BWD_LDS_BYTES);                                                  \
     } while (0)
     if (feats != nullptr) {                      // no gather in the kernel: the table type does not matter
         if (desc->compute_dtype == NSR_F16) NSR_BWD_LAUNCH(float, NSR_F16, true);
@@ -730,6 +899,7 @@ int nsr_field_backward(const nsr_field_desc *desc, const void *tables, const flo
         if (desc->table_dtype == NSR_F16 && desc->compute_dtype == NSR_BF16) NSR_BWD_LAUNCH(_Float16, NSR_BF16, false);
     }
 #undef NSR_BWD_LAUNCH
+#undef NSR_BWD_LAUNCH_
     return NSR_ERR_UNSUPPORTED;
 }
 

@@ -32,6 +32,7 @@ struct FieldArgs {
     float *sigmas;
     float *rgbs;
     void *feats;          // optional [ntiles][64 lanes][2] x 16 B: (xd, xc) B fragments per lane
+    const uint32_t *perm; // optional [M]: tile t works on samples perm[16t .. 16t+15] (nsr_sample_order); feats stay tile-major
     float bmin[3], bsize[3];
     float density_scale;
     uint32_t C_ch;

@@ -74,7 +74,7 @@ class _field(Function):
     is arena.grad) and returns None for it."""
 
     @staticmethod
-    def forward(ctx, xyzs, arena, model, sigma_only, m_dev, density_scale, want_feats=False):
+    def forward(ctx, xyzs, arena, model, sigma_only, m_dev, density_scale, want_feats=False, perm=None):
         xyzs = xyzs.detach().to(torch.float32).contiguous()
         M = xyzs.shape[0]
         dev = xyzs.device
@@ -89,9 +89,11 @@ class _field(Function):
             feats = torch.empty(((M + 15) // 16) * 512, dtype=torch.int32, device=dev)
         with profiling.timed('field_fwd_sigma' if sigma_only else 'field_fwd'):
             L.check(L.lib().nsr_field_forward(ctypes.byref(desc), L.p(tables), L.p(model._mlp_flat()),
-                                              L.p(xyzs), M, L.p(m_dev), L.p(sigmas), L.p(rgbs), L.p(feats), L.stream()),
+                                              L.p(xyzs), M, L.p(m_dev), L.p(sigmas), L.p(rgbs), L.p(feats), L.p(perm),
+                                              L.stream()),
                     'field_forward')
         ctx.feats = feats
+        ctx.perm = perm
         ctx.model = model
         ctx.m_dev = m_dev
         ctx.density_scale = density_scale
@@ -121,8 +123,9 @@ class _field(Function):
             L.check(L.lib().nsr_field_backward(
                 ctypes.byref(desc), L.p(tables), L.p(model._mlp_flat()), L.p(xyzs), M, L.p(ctx.m_dev),
                 L.p(grad_sigmas), L.p(grad_rgbs), L.p(ga), ga.data_ptr() + model.table_elems * 4,
-                int(model.train_density_table), int(model.train_color_table), L.p(ctx.feats), L.stream()), 'field_backward')
-        return None, None, None, None, None, None, None
+                int(model.train_density_table), int(model.train_color_table), L.p(ctx.feats), L.p(ctx.perm), L.stream()),
+                'field_backward')
+        return None, None, None, None, None, None, None, None
 
 
 class _EncoderView(nn.Module):
@@ -313,10 +316,31 @@ class StyleTCNerf(nn.Module):
         return out
 
     # ---- forward -------------------------------------------------------------------------------
-    def field(self, pts, sigma_only=False, m_dev=None, density_scale=1.0):
-        """Fast path: flat sigmas [M] (and rgbs [M,3+nc]); m_dev = device int32 sample count."""
+    def field(self, pts, sigma_only=False, m_dev=None, density_scale=1.0, perm=None):
+        """Fast path: flat sigmas [M] (and rgbs [M,3+nc]); m_dev = device int32 sample count; perm = spatial processing
+        order from `sample_order` (int32/uint32 [M] device tensor) -- same results, cache- and atomic-friendlier."""
         want_feats = bool(self.save_features and torch.is_grad_enabled() and self.arena.requires_grad and not sigma_only)
-        return _field.apply(pts, self.arena, self, sigma_only, m_dev, density_scale, want_feats)
+        return _field.apply(pts, self.arena, self, sigma_only, m_dev, density_scale, want_feats, perm)
+
+    def sample_order(self, xyzs, m_dev=None, sort_prefix=None):
+        """nsr_sample_order: Morton-order permutation of the samples [M,3] (int32 tensor [M], a uint32 bit pattern)."""
+        M = xyzs.shape[0]
+        dev = xyzs.device
+        key = (M, str(dev))
+        if getattr(self, '_order_key', None) != key:
+            nbytes = int(L.lib().nsr_sample_order_workspace_bytes(M))
+            self._order_ws = torch.empty((nbytes + 3) // 4 + 64, dtype=torch.int32, device=dev)
+            self._order_key = key
+        ws = self._order_ws
+        ws_ptr = (ws.data_ptr() + 255) & ~255
+        perm = torch.empty(M, dtype=torch.int32, device=dev)
+        if getattr(self, '_bbox_host', None) is None:
+            self._desc()
+        mn, sz = self._bbox_host
+        c3 = ctypes.c_float * 3
+        L.check(L.lib().nsr_sample_order(L.p(xyzs), M, L.p(m_dev), M if sort_prefix is None else int(min(sort_prefix, M)),
+                                         c3(*mn), c3(*sz), L.p(perm), ws_ptr, L.stream()), 'sample_order')
+        return perm
 
     def forward(self, pts, dirs=None, bsize=1000000):
         """style_nerf.py:144-159.  The >1M-point chunking of the reference (utils.batch_exec) is

@@ -261,15 +261,16 @@ def test_field_backward(O, dev, dt, table_dtype):
     assert np.all(gt2[:, 0, :] == 0) and rel_l2(gt2[:, 1, :], gt[:, 1, :]) < 1e-3
 
 
-@pytest.mark.parametrize('min_res', [16, 2])
-def test_field_backward_run_tracker_on_ray_structured_samples(O, dev, min_res):
+@pytest.mark.parametrize('min_res,sorted_walk', [(16, False), (2, False), (16, True), (2, True)])
+def test_field_backward_run_tracker_on_ray_structured_samples(O, dev, min_res, sorted_walk):
     """The backward's scatter keeps the open run of every (level, corner) in registers along CONSECUTIVE
     samples and hands runs over when a sample moves one cell along one axis (field_bwd.hip,
     field_scatter_seq).  Random points never exercise that, so: samples marching along rays with steps from
     far below a fine cell to several coarse cells, axis-aligned rays in both directions (pure x / y / z
     hand-overs), samples that stand still, samples outside the box in between (dead lanes), ray ends in
     the middle of 16-sample tiles.  min_res = 2 makes the coarsest levels dense (use_hash = 0) and not a
-    power of two."""
+    power of two.  sorted_walk: the same samples walked in the spatial order of nsr_sample_order, scattered by the
+    LDS lattice accumulator instead (field_scatter_lattice): tile changes on every level, dead samples in between."""
     m, ref = _field_pair(dev, 'f16', torch.float32, min_res=min_res)
     assert int(m.x_density_embedder.offsets[-1]) == int(ref.offsets[-1])
     rng = np.random.default_rng(7 + min_res)
@@ -304,7 +305,8 @@ def test_field_backward_run_tracker_on_ray_structured_samples(O, dev, min_res):
     gr = rng.standard_normal((M, 8)).astype(np.float32)
     gr[rng.random(M) < 0.2] = 0.0                         # zero upstream gradients on a fifth of the samples
     gs[rng.random(M) < 0.2] = 0.0
-    sig, rgbs = m.field(T(pts, dev), False)
+    perm = m.sample_order(T(pts, dev)) if sorted_walk else None
+    sig, rgbs = m.field(T(pts, dev), False, perm=perm)
     ((sig * T(gs, dev)).sum() + (rgbs * T(gr, dev)).sum()).backward()
     # the restatement applies the reference's own out-of-range rule (zero features, gridencoder.cu:118-131): the
     # encoder input is (x_hat + 1) / 2, so points down to -6 on an axis are still encoded, points above +2 are not
@@ -319,6 +321,86 @@ def test_field_backward_run_tracker_on_ray_structured_samples(O, dev, min_res):
     for l in range(16):
         a, b = gt[off[l]:off[l + 1], 1, :], ref.emb_color.grad.numpy()[off[l]:off[l + 1]]
         assert rel_l2(a, b) < 1e-2, l
+
+
+def _march_samples(O, dev, n_rays, cap):
+    """ray-marched samples of the small scene in a capacity-sized buffer + device-side count"""
+    from nerfstyle_amd import raymarching as R
+    from helpers import room_rays, small_scene
+    grid, bits = small_scene()
+    ro, rd = room_rays(O, n_rays, seed=3)
+    aabb = T(np.array([-2, -2, -2, 2, 2, 2], np.float32), dev)
+    near, far = R.near_far_from_aabb(T(ro, dev), T(rd, dev), aabb, 0.2)
+    counter = torch.zeros(2, dtype=torch.int32, device=dev)
+    xyzs, _, deltas, rays = R.march_rays_train_nosync(T(ro, dev), T(rd, dev), 2.0, T(bits, dev), 2, 128, near, far, n_rays * cap,
+                                                      counter, 0., 1024)
+    return xyzs, counter
+
+
+@pytest.mark.parametrize('dt,table_dtype', [('f16', None), ('bf16', torch.float32)])
+def test_sample_order_and_sorted_walk_equal_buffer_order(O, dev, dt, table_dtype):
+    """nsr_sample_order + the `perm` argument of the fused field: the permutation is a bijection of the valid slots in
+    non-decreasing Morton key order (stable), whatever sort_prefix is; the forward through it is BIT-identical per
+    sample; the backward (lattice accumulator) equals the buffer-order backward (run tracker) up to fp32 summation
+    order, with saved features and with the re-gather path, and with only the colour table trained."""
+    m, ref = _field_pair(dev, dt, table_dtype)
+    xyzs, counter = _march_samples(O, dev, 3000, 160)
+    M, cnt = xyzs.shape[0], int(counter[0])
+    assert 16 * 3000 < cnt < M
+    xyzs[cnt:] = float('nan')                                   # capacity tail: never read
+    x = xyzs[:cnt].cpu().numpy()
+    u = ((x + 2.0) / 4.0 + 1.0) * 0.5
+    q = np.clip(u * 1024.0, 0, 1023).astype(np.uint32)
+
+    def spread(v):
+        v = v.astype(np.uint64) & 0x3FF
+        v = (v | (v << 16)) & 0x030000FF
+        v = (v | (v << 8)) & 0x0300F00F
+        v = (v | (v << 4)) & 0x030C30C3
+        v = (v | (v << 2)) & 0x09249249
+        return v
+    key = spread(q[:, 0]) | (spread(q[:, 1]) << 1) | (spread(q[:, 2]) << 2)
+    want = np.argsort(key, kind='stable')
+    for prefix in (None, cnt + 1000, cnt // 2, 0):
+        perm = m.sample_order(xyzs, m_dev=counter, sort_prefix=prefix)
+        ph = perm.cpu().numpy().astype(np.int64)
+        assert np.array_equal(np.sort(ph), np.arange(M))                         # a permutation of every slot
+        assert np.array_equal(np.sort(ph[:cnt]), np.arange(cnt))                # valid samples first
+        if prefix is None or prefix >= cnt:
+            assert np.array_equal(ph[:cnt], want)                                # stable Morton order
+        elif prefix > 0:
+            assert np.all(np.diff(key[ph[:prefix]].astype(np.int64)) >= 0) and np.array_equal(ph[prefix:], np.arange(prefix, M))
+        else:
+            assert np.array_equal(ph, np.arange(M))
+    perm = m.sample_order(xyzs, m_dev=counter, sort_prefix=cnt + 4096)
+    g = torch.Generator(device=dev)
+    g.manual_seed(1)
+    gs = torch.randn(M, device=dev, generator=g) * 1e-2
+    gr = torch.randn(M, 8, device=dev, generator=g)
+
+    def run(p, feats=True, density=True):
+        m.arena.grad = None
+        m.grad_arena = None
+        m.save_features, m.train_density_table = feats, density
+        sig, rgb = m.field(xyzs, False, counter, perm=p)
+        torch.autograd.backward([sig, rgb], [gs, gr])
+        m.save_features, m.train_density_table = True, True
+        return sig.detach()[:cnt].clone(), rgb.detach()[:cnt].clone(), m.arena.grad.detach().clone()
+    s0, r0, g0 = run(None)
+    s1, r1, g1 = run(perm)
+    assert torch.equal(s0, s1) and torch.equal(r0, r1)                           # per-sample results do not depend on the walk
+    assert float(g0.abs().sum()) > 0
+    assert rel_l2(g1.cpu().numpy(), g0.cpu().numpy()) < 2e-5
+    assert int(((g1 == 0) != (g0 == 0)).sum()) < 10                              # the scatter goes exactly where the gather went
+    _, _, g2 = run(perm, feats=False)
+    assert rel_l2(g2.cpu().numpy(), g0.cpu().numpy()) < 2e-5
+    _, _, g3 = run(perm, density=False)
+    t3, t0 = g3[:m.table_elems].view(m.rows, 2, 2), g0[:m.table_elems].view(m.rows, 2, 2)
+    assert float(t3[:, 0].abs().max()) == 0.0 and rel_l2(t3[:, 1].cpu().numpy(), t0[:, 1].cpu().numpy()) < 2e-5
+    # sigma-only forward through the permutation
+    with torch.no_grad():
+        s_only = m.field(xyzs, True, counter, perm=perm)
+    assert torch.equal(s_only[:cnt], s0)
 
 
 @pytest.mark.parametrize('nc', [1, 13])
