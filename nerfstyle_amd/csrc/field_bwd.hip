@@ -37,6 +37,11 @@ constexpr size_t BWD_QUEUE_BYTES_PER_WAVE = 1024 * 16 + 1024 * 4 + 16 * 16 * 16;
 constexpr size_t BWD_LDS_BYTES = (size_t)FW_TOTAL * 2 + (size_t)BW_TOTAL * 2 + 16 * sizeof(NsrLevel) +
                                  (BWD_THREADS / 64) * BWD_QUEUE_BYTES_PER_WAVE;
 
+struct LatGeom {
+    uint16_t base[16];      // first slot of the level's lattice
+    uint8_t S[16];          // corners per axis
+};
+
 struct FieldBwdArgs {
     FieldArgs f;
     const float *grad_sigmas;
@@ -45,6 +50,7 @@ struct FieldBwdArgs {
     float *grad_mlp;
     int train_density, train_color;
     uint32_t nc;
+    LatGeom lat;               // SORTED kernels: lattice geometry (lat_geometry)
 };
 
 template <int CD>
@@ -351,63 +357,109 @@ __device__ __forceinline__ void field_scatter_seq(SeqState &st, const NsrLevel *
 // ---------------------------------------------------------------------------------------------------------
 // Lattice accumulator (SORTED kernels: samples walked in the spatial order of nsr_sample_order).
 //
-// In Morton order consecutive samples -- of MANY rays -- sit in the same few cells on every level, so the wave keeps,
-// per level, the corner gradients of one aligned TILE of cells in LDS: 4^3 cells (5^3 = 125 corners) on the fine
-// levels, 2^3 cells (27 corners) on the coarse ones, 17 KB per wave.  Lane = (level l = lane >> 2, y/z corner pair
+// The order's key is the sample's BLOCK: its encoder input quantised to 10 bits per axis (a 4^3 group of finest-level
+// cells for the reference's 16-level grid).  Consecutive samples -- of MANY rays -- share a block, and a block touches
+// only a handful of cells on every level: at most ceil(res_l / 1024) + 1 per axis.  So the wave keeps, per level, a
+// small LATTICE of corner gradients in LDS anchored at the cell of the block's origin (5^3 corners on the two finest
+// levels, 4^3 on the next two, 3^3 below: 702 float4 = 11 KB per wave).  Lane = (level l = lane >> 2, y/z corner pair
 // p = lane & 3) walks the tile's 16 samples in order and adds its two x corners' contributions with a plain LDS
-// read-modify-write -- no atomics are needed: within a step the 64 lanes touch 128 different lattice slots, and steps
-// are sequential.  No hashing per sample either: the lattice is addressed by cell coordinates; rows are computed only
-// when a level's tile is left and its touched corners are flushed, one merged record per corner (tools/
-// sorted_scatter_sim.py: 11.7 records and 5.9 atomic requests per sample on the bench scene against 29.7 / 19.3 of
-// the ray-order run tracker, at a third of its instructions).  A flush is cooperative: 16 corners per
-// wave-instruction, 4 lanes per corner, so the four dwords of a row leave as ONE 16-byte request and the x-aligned
-// corners of a row group (tile origin is a multiple of 4 cells) share their 64-byte line.
-constexpr int LAT_FINE0 = 10;                        // levels >= LAT_FINE0: 4^3-cell tiles; below: 2^3-cell tiles
-constexpr int LAT_COARSE_SLOTS = 32, LAT_FINE_SLOTS = 128;
-constexpr int LAT_TOTAL = LAT_FINE0 * LAT_COARSE_SLOTS + (16 - LAT_FINE0) * LAT_FINE_SLOTS;   // float4 slots per wave
-constexpr size_t BWD_LAT_BYTES_PER_WAVE = (size_t)LAT_TOTAL * 16 + 16 * 16 * 16;                // lattice + staging
+// read-modify-write: within a step the 64 lanes touch 128 different slots and steps are sequential, so no atomics
+// are needed; the lattice is addressed by cell coordinates, so nothing is hashed per sample.  When the walk enters
+// a new block every level re-anchors; a level whose anchor cell did not change (the coarse ones: a block is a
+// fraction of their cell) keeps accumulating, the others are flushed cooperatively -- 16 corners per wave-instruction,
+// 4 lanes per corner, so the four dwords of a row leave as ONE 16-byte request, one merged record per corner a block
+// touched (tools/sorted_scatter_sim.py: ~6 records and ~3 atomic requests per sample on the bench scene against
+// 29.7 / 19.3 of the ray-order run tracker, at a third of its instructions).
+constexpr int LAT_MAX_SLOTS = 1024;                  // float4 slots per wave (16 KB)
+constexpr int LAT_KEY_BITS = 10;                     // must match nsr_sample_order's quantisation
+constexpr size_t BWD_LAT_BYTES_PER_WAVE = (size_t)LAT_MAX_SLOTS * 16 + 16 * 16 * 16;           // lattice + staging
 constexpr size_t BWD_LDS_BYTES_SORTED = (size_t)FW_TOTAL * 2 + (size_t)BW_TOTAL * 2 + 16 * sizeof(NsrLevel) +
                                         (BWD_THREADS / 64) * BWD_LAT_BYTES_PER_WAVE;
 constexpr uint32_t LAT_NONE = 0xFFFFFFFFu;
-__device__ __forceinline__ int lat_base(int l) {
-    return l < LAT_FINE0 ? l * LAT_COARSE_SLOTS : LAT_FINE0 * LAT_COARSE_SLOTS + (l - LAT_FINE0) * LAT_FINE_SLOTS;
-}
 struct LatState {
-    uint32_t t0, t1, t2;     // tile (cell >> log2 T) this lane's level is accumulating; LAT_NONE: nothing yet
+    uint32_t b0, b1, b2;     // anchor cell of this lane's level (LAT_NONE: nothing accumulated yet)
 };
 
-// Flushes level l's tile (t0, t1, t2) -- wave-uniform arguments -- and clears it.
-template <int LOG2T>
-__device__ __forceinline__ void lat_flush_level(float4 *__restrict__ lat, int l, uint32_t t0, uint32_t t1, uint32_t t2,
-                                                const NsrLevel &lv, float *__restrict__ gt, int lane, bool td, bool tc) {
-    constexpr int T = 1 << LOG2T, S = T + 1, NC = S * S * S;
-    float *lf = reinterpret_cast<float *>(lat + lat_base(l));
+// Host: lattice geometry for the 1/1024 blocks of the sample order.  A block spans e = res / 1024 cells of a level:
+// it touches at most floor(e) + 2 cells per axis (exactly e when the level's cells tile the block), one more corner.
+static bool lat_geometry(const NsrLevel *lv, LatGeom &g) {
+    uint32_t total = 0;
+    for (int l = 0; l < 16; l++) {
+        const uint32_t res = lv[l].resolution, blocks = 1u << LAT_KEY_BITS;
+        const uint32_t cells = (res % blocks == 0) ? res / blocks : res / blocks + 2;
+        const uint32_t S = cells + 1;
+        if (S > 6) return false;
+        g.S[l] = (uint8_t)S;
+        g.base[l] = (uint16_t)total;
+        total += S * S * S;
+    }
+    return total <= (uint32_t)LAT_MAX_SLOTS;
+}
+
+// Flushes level l's lattice, anchored at cell (b0, b1, b2) -- wave-uniform arguments -- and clears it.
+template <int S>
+__device__ __forceinline__ void lat_flush_level(float *__restrict__ lf, uint32_t b0, uint32_t b1, uint32_t b2, const NsrLevel &lv,
+                                                float *__restrict__ gt, int lane, bool td, bool tc) {
+    constexpr int NC = S * S * S;
     const int t = lane >> 2, i = lane & 3;
     const bool on = (i < 2) ? td : tc;
+    // two groups of 16 corners per trip: both LDS reads are in flight before either is used (one wave per SIMD:
+    // a dependent LDS round trip per group would be fully exposed)
 #pragma unroll 1
-    for (int k0 = 0; k0 < NC; k0 += 16) {
-        const int k = k0 + t;
-        float v = 0.0f;
-        if (k < NC) v = lf[k * 4 + i];
-        const unsigned long long nzm = __ballot(v != 0.0f);
-        if ((nzm >> (lane & ~3)) & 0xFull) {                 // any component of this corner is non-zero
-            const int z = k / (S * S), r = k - z * (S * S), y = r / S, x = r - y * S;
-            const uint32_t row = lv.offset + nsr_grid_row(lv, t0 * T + (uint32_t)x, t1 * T + (uint32_t)y, t2 * T + (uint32_t)z, 0u);
+    for (int k0 = 0; k0 < NC; k0 += 32) {
+        const int ka = k0 + t, kb = k0 + 16 + t;
+        const float va = ka < NC ? lf[ka * 4 + i] : 0.0f;
+        const float vb = kb < NC ? lf[kb * 4 + i] : 0.0f;
+        const unsigned long long ma = __ballot(va != 0.0f), mb = __ballot(vb != 0.0f);
+        const bool ra = (ma >> (lane & ~3)) & 0xFull, rb = (mb >> (lane & ~3)) & 0xFull;   // any component of the corner non-zero
+        if (ra) {
+            const int z = ka / (S * S), r = ka - z * (S * S), y = r / S, x = r - y * S;
+            const uint32_t row = lv.offset + nsr_grid_row(lv, b0 + (uint32_t)x, b1 + (uint32_t)y, b2 + (uint32_t)z, 0u);
 #ifndef NSR_ABL_NO_ATOMIC
-            if (on) atomicAdd(gt + (size_t)row * 4 + i, v);
+            if (on) atomicAdd(gt + (size_t)row * 4 + i, va);
 #else
-            if (on && row == 0xFFFFFFFFu) gt[i] = v;
+            if (on && row == 0xFFFFFFFFu) gt[i] = va;
 #endif
-            lf[k * 4 + i] = 0.0f;
+            lf[ka * 4 + i] = 0.0f;
         }
+        if (rb) {
+            const int z = kb / (S * S), r = kb - z * (S * S), y = r / S, x = r - y * S;
+            const uint32_t row = lv.offset + nsr_grid_row(lv, b0 + (uint32_t)x, b1 + (uint32_t)y, b2 + (uint32_t)z, 0u);
+#ifndef NSR_ABL_NO_ATOMIC
+            if (on) atomicAdd(gt + (size_t)row * 4 + i, vb);
+#else
+            if (on && row == 0xFFFFFFFFu) gt[i] = vb;
+#endif
+            lf[kb * 4 + i] = 0.0f;
+        }
+    }
+}
+
+// The geometry of level fl comes from the LDS copy of the level table (pad_ = S | base << 8): a read from the
+// kernel-argument segment here would be a vector-memory load, and waiting for it means waiting for every atomic in flight.
+__device__ __forceinline__ void lat_flush_dispatch(float4 *__restrict__ lat, int fl, const LatState &st,
+                                                   const NsrLevel *__restrict__ lds_lv, float *__restrict__ gt, int lane, bool td, bool tc) {
+    const uint32_t o0 = (uint32_t)__builtin_amdgcn_readlane((int)st.b0, fl * 4);
+    if (o0 == LAT_NONE) return;
+    const uint32_t o1 = (uint32_t)__builtin_amdgcn_readlane((int)st.b1, fl * 4);
+    const uint32_t o2 = (uint32_t)__builtin_amdgcn_readlane((int)st.b2, fl * 4);
+    const NsrLevel flv = lds_lv[fl];
+    float *lf = reinterpret_cast<float *>(lat + (flv.pad_ >> 8));
+    switch (flv.pad_ & 0xFFu) {
+    case 3: lat_flush_level<3>(lf, o0, o1, o2, flv, gt, lane, td, tc); break;
+    case 4: lat_flush_level<4>(lf, o0, o1, o2, flv, gt, lane, td, tc); break;
+    case 5: lat_flush_level<5>(lf, o0, o1, o2, flv, gt, lane, td, tc); break;
+    default: lat_flush_level<6>(lf, o0, o1, o2, flv, gt, lane, td, tc); break;
     }
 }
 
 // One tile of 16 (spatially ordered) samples.  G: this wave's [16 levels][16 samples] float4 staging buffer; (u0,u1,u2):
 // this lane's SAMPLE (lane & 15) position; sg[i]: its gradients for level lvl[i]; live: this lane's sample is inside.
-__device__ __forceinline__ void field_scatter_lattice(LatState &st, const NsrLevel *__restrict__ lds_lv, float4 *__restrict__ G,
+__device__ __forceinline__ void field_scatter_lattice(LatState &st, uint32_t &cur_key,
+                                                      const NsrLevel *__restrict__ lds_lv, float4 *__restrict__ G,
                                                       float4 *__restrict__ lat, float *__restrict__ gt, float u0, float u1, float u2,
-                                                      bool live, const float4 (&sg)[4], int lane, bool td, bool tc) {
+                                                      bool live, const float4 (&sg)[4], int lane, bool td, bool tc,
+                                                      uint32_t myS, uint32_t mybase) {
 #ifdef NSR_ABL_NO_SCATTER
     if (lane >= 0) return;
 #endif
@@ -416,16 +468,41 @@ __device__ __forceinline__ void field_scatter_lattice(LatState &st, const NsrLev
 #pragma unroll
     for (int i = 0; i < 4; i++) G[lvl[i] * 16 + s] = sg[i];
     const uint32_t live16 = (uint32_t)(__ballot(live) & 0xFFFFull);      // lanes 0..15 are samples 0..15
+    // this lane's sample's block: the sort key's quantisation (sample_order.hip), 10 bits per axis
+    const float kq = (float)(1 << LAT_KEY_BITS);
+    const uint32_t q0 = (uint32_t)fminf(fmaxf(u0 * kq, 0.0f), kq - 1.0f), q1 = (uint32_t)fminf(fmaxf(u1 * kq, 0.0f), kq - 1.0f),
+                   q2 = (uint32_t)fminf(fmaxf(u2 * kq, 0.0f), kq - 1.0f);
+    const uint32_t bkey = q0 | (q1 << LAT_KEY_BITS) | (q2 << (2 * LAT_KEY_BITS));
     __builtin_amdgcn_wave_barrier();
     const int l = lane >> 2, py = lane & 1, pz = (lane >> 1) & 1;
     const NsrLevel lv = lds_lv[l];
-    const bool fine = l >= LAT_FINE0;
-    const uint32_t sh = fine ? 2u : 1u, msk = fine ? 3u : 1u, S = fine ? 5u : 3u;
-    float4 *const mylat = lat + lat_base(l) + ((uint32_t)pz * S + (uint32_t)py) * S;
-#pragma unroll
+    const uint32_t S = myS;
+    float4 *const mylat = lat + mybase + ((uint32_t)pz * S + (uint32_t)py) * S;
+#pragma unroll 2
     for (int step = 0; step < 16; step++) {
         if (!((live16 >> step) & 1u)) continue;                            // wave-uniform
         const float4 gr = G[l * 16 + step];
+        const uint32_t key = (uint32_t)__builtin_amdgcn_readlane((int)bkey, step);
+        if (key != cur_key) {
+            // ---- the walk enters another block: re-anchor every level at the cell of the block's origin ----
+            cur_key = key;
+            const float rk = 1.0f / kq;
+            const float o0 = (float)(key & ((1u << LAT_KEY_BITS) - 1u)) * rk, o1 = (float)((key >> LAT_KEY_BITS) & ((1u << LAT_KEY_BITS) - 1u)) * rk,
+                        o2 = (float)(key >> (2 * LAT_KEY_BITS)) * rk;
+            float ff;
+            uint32_t n0, n1, n2;
+            nsr_grid_locate(o0, lv.resolution, 1, ff, n0);
+            nsr_grid_locate(o1, lv.resolution, 1, ff, n1);
+            nsr_grid_locate(o2, lv.resolution, 1, ff, n2);
+            const bool chg = (n0 != st.b0) | (n1 != st.b1) | (n2 != st.b2);
+            unsigned long long mm = __ballot(chg);
+            while (mm) {
+                const int fl = (int)(__builtin_ctzll(mm) >> 2);
+                mm &= ~(0xFull << (fl * 4));
+                lat_flush_dispatch(lat, fl, st, lds_lv, gt, lane, td, tc);
+            }
+            if (chg) { st.b0 = n0; st.b1 = n1; st.b2 = n2; }
+        }
         const float su0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, u0), step));
         const float su1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, u1), step));
         const float su2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, u2), step));
@@ -434,28 +511,31 @@ __device__ __forceinline__ void field_scatter_lattice(LatState &st, const NsrLev
         nsr_grid_locate(su0, lv.resolution, 1, f0, c0);
         nsr_grid_locate(su1, lv.resolution, 1, f1, c1);
         nsr_grid_locate(su2, lv.resolution, 1, f2, c2);
-        const uint32_t n0 = c0 >> sh, n1 = c1 >> sh, n2 = c2 >> sh;
-        const bool chg = (n0 != st.t0) | (n1 != st.t1) | (n2 != st.t2);
-        unsigned long long mm = __ballot(chg);
-        if (mm) {                                                          // some level leaves its tile
-            do {
-                const int fl = (int)(__builtin_ctzll(mm) >> 2);
-                mm &= ~(0xFull << (fl * 4));
-                const uint32_t o0 = (uint32_t)__builtin_amdgcn_readlane((int)st.t0, fl * 4);
-                if (o0 != LAT_NONE) {
-                    const uint32_t o1 = (uint32_t)__builtin_amdgcn_readlane((int)st.t1, fl * 4);
-                    const uint32_t o2 = (uint32_t)__builtin_amdgcn_readlane((int)st.t2, fl * 4);
-                    const NsrLevel flv = lds_lv[fl];
-                    if (fl >= LAT_FINE0) lat_flush_level<2>(lat, fl, o0, o1, o2, flv, gt, lane, td, tc);
-                    else lat_flush_level<1>(lat, fl, o0, o1, o2, flv, gt, lane, td, tc);
-                }
-            } while (mm);
-            if (chg) { st.t0 = n0; st.t1 = n1; st.t2 = n2; }
-        }
+        // cell relative to the anchor: 0 .. S - 2 by construction (the sample lies in the block the anchor was taken from;
+        // floor(u * res) is monotonic in u).  The clamp only keeps a violated assumption inside the wave's own LDS.
+        const uint32_t d0 = c0 - st.b0, d1 = c1 - st.b1, d2 = c2 - st.b2;
+        const uint32_t r0 = min(d0, S - 2u), r1 = min(d1, S - 2u), r2 = min(d2, S - 2u);
         // this sample's contribution to the lane's two x corners: (wx*wy)*wz, the product order of the forward
         const float wy = py ? f1 : 1 - f1, wz = pz ? f2 : 1 - f2;
-        const float wA = ((1 - f0) * wy) * wz, wB = (f0 * wy) * wz;
-        float4 *const slot = mylat + (((c2 & msk) * S + (c1 & msk)) * S + (c0 & msk));
+        float wA = ((1 - f0) * wy) * wz, wB = (f0 * wy) * wz;
+        if ((d0 | d1 | d2) > S - 2u && max(d0, max(d1, d2)) > S - 2u) {
+            // fp32 rounding put the cell one past the lattice (u * res of a sample at the very end of its block can round
+            // up across a cell boundary that the block's real extent stops short of): this sample's two corners go
+            // straight to the table, exactly; the (clamped) lattice slots get nothing
+            const uint32_t rowA = lv.offset + nsr_grid_row(lv, c0, c1 + (uint32_t)py, c2 + (uint32_t)pz, 0u);
+            const uint32_t rowB = lv.offset + nsr_grid_row(lv, c0 + 1u, c1 + (uint32_t)py, c2 + (uint32_t)pz, 0u);
+            const float ga[4] = {gr.x, gr.y, gr.z, gr.w};
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                if ((i < 2 ? td : tc) && ga[i] != 0.0f) {
+                    atomicAdd(gt + (size_t)rowA * 4 + i, wA * ga[i]);
+                    atomicAdd(gt + (size_t)rowB * 4 + i, wB * ga[i]);
+                }
+            }
+            wA = 0.0f;
+            wB = 0.0f;
+        }
+        float4 *const slot = mylat + ((r2 * S + r1) * S + r0);
         float4 a = slot[0], b = slot[1];
         a.x = fmaf(wA, gr.x, a.x); a.y = fmaf(wA, gr.y, a.y); a.z = fmaf(wA, gr.z, a.z); a.w = fmaf(wA, gr.w, a.w);
         b.x = fmaf(wB, gr.x, b.x); b.y = fmaf(wB, gr.y, b.y); b.z = fmaf(wB, gr.z, b.z); b.w = fmaf(wB, gr.w, b.w);
@@ -464,21 +544,13 @@ __device__ __forceinline__ void field_scatter_lattice(LatState &st, const NsrLev
     }
 }
 
-// End of a wave's tile range: every level's open tile leaves.
-__device__ __forceinline__ void field_scatter_lattice_finish(LatState &st, const NsrLevel *__restrict__ lds_lv, float4 *__restrict__ lat,
-                                                             float *__restrict__ gt, int lane, bool td, bool tc) {
+// End of a wave's tile range: every level's lattice leaves.
+__device__ __forceinline__ void field_scatter_lattice_finish(LatState &st, const NsrLevel *__restrict__ lds_lv,
+                                                             float4 *__restrict__ lat, float *__restrict__ gt, int lane, bool td, bool tc) {
     __builtin_amdgcn_wave_barrier();
 #pragma unroll 1
-    for (int fl = 0; fl < 16; fl++) {
-        const uint32_t o0 = (uint32_t)__builtin_amdgcn_readlane((int)st.t0, fl * 4);
-        if (o0 == LAT_NONE) continue;
-        const uint32_t o1 = (uint32_t)__builtin_amdgcn_readlane((int)st.t1, fl * 4);
-        const uint32_t o2 = (uint32_t)__builtin_amdgcn_readlane((int)st.t2, fl * 4);
-        const NsrLevel flv = lds_lv[fl];
-        if (fl >= LAT_FINE0) lat_flush_level<2>(lat, fl, o0, o1, o2, flv, gt, lane, td, tc);
-        else lat_flush_level<1>(lat, fl, o0, o1, o2, flv, gt, lane, td, tc);
-    }
-    st.t0 = st.t1 = st.t2 = LAT_NONE;
+    for (int fl = 0; fl < 16; fl++) lat_flush_dispatch(lat, fl, st, lds_lv, gt, lane, td, tc);
+    st.b0 = st.b1 = st.b2 = LAT_NONE;
 }
 
 // FEATS: the forward saved the encoder outputs (the default).  Compile-time because the re-gather path, though
@@ -495,7 +567,11 @@ k_field_bwd(FieldBwdArgs b) {
     const FieldArgs &a = b.f;
     field_build_fw<CD, false>(wl, a.params);
     field_build_bw<CD>(wt, a.params);
-    if (threadIdx.x < 16) lds_lv[threadIdx.x] = a.lv[threadIdx.x];
+    if (threadIdx.x < 16) {
+        NsrLevel v = a.lv[threadIdx.x];
+        if (SORTED) v.pad_ = (uint32_t)b.lat.S[threadIdx.x] | ((uint32_t)b.lat.base[threadIdx.x] << 8);
+        lds_lv[threadIdx.x] = v;
+    }
     __syncthreads();
 
     const uint32_t Mc = a.m_dev ? min((uint32_t)max(a.m_dev[0], 0), a.M) : a.M;
@@ -518,8 +594,8 @@ k_field_bwd(FieldBwdArgs b) {
     if (SORTED) {
         char *base = wave_lds + (size_t)wave * BWD_LAT_BYTES_PER_WAVE;
         lat = reinterpret_cast<float4 *>(base);
-        qbase_g = base + (size_t)LAT_TOTAL * 16;
-        for (int k = lane; k < LAT_TOTAL; k += 64) lat[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        qbase_g = base + (size_t)LAT_MAX_SLOTS * 16;
+        for (int k = lane; k < LAT_MAX_SLOTS; k += 64) lat[k] = make_float4(0.f, 0.f, 0.f, 0.f);
     } else {
         char *qbase = wave_lds + (size_t)wave * BWD_QUEUE_BYTES_PER_WAVE;
         q.vals = reinterpret_cast<float4 *>(qbase);
@@ -532,7 +608,9 @@ k_field_bwd(FieldBwdArgs b) {
     seq.kA = seq.kB = 0u;
     seq.aA = seq.aB = make_float4(0.f, 0.f, 0.f, 0.f);
     LatState latst;
-    latst.t0 = latst.t1 = latst.t2 = LAT_NONE;
+    latst.b0 = latst.b1 = latst.b2 = LAT_NONE;
+    uint32_t lat_key = LAT_NONE;
+    const uint32_t lat_myS = SORTED ? (lds_lv[lane >> 2].pad_ & 0xFFu) : 0u, lat_mybase = SORTED ? (lds_lv[lane >> 2].pad_ >> 8) : 0u;
     float4 *const seqG = reinterpret_cast<float4 *>(qbase_g);        // [16 levels][16 samples] float4 staging, 4 KB
     const bool td = b.train_density != 0, tc = b.train_color != 0;
     float *const gt1 = b.grad_tables - 4;      // ring rows are stored +1 (field_scatter_level)
@@ -563,10 +641,13 @@ k_field_bwd(FieldBwdArgs b) {
         float grgb[4];     // grad_rgbs[m, 4g .. 4g+3]
     };
     // position `16 * tile + s` of the walk -> index into the sample buffers (0 for lanes past the count)
+    // (SORTED: one unconditional load -- a select between a loaded and a computed value would make the compiler wait
+    // for the load, and with it for every other load in flight, right where it is issued; lanes past the count read the
+    // last valid entry and are masked where the data is used.  The launcher guarantees perm != NULL for SORTED kernels.)
     auto fetch_idx = [&](uint32_t tile) -> uint32_t {
         const uint32_t m = tile * 16 + s;
-        if (m >= Mc) return 0u;
-        return (SORTED && a.perm) ? a.perm[m] : m;
+        if (SORTED) return a.perm[min(m, Mc - 1u)];
+        return m < Mc ? m : 0u;
     };
     auto load_tile = [&](uint32_t tile, uint32_t buf_idx) {
         TileIn r;
@@ -621,6 +702,15 @@ k_field_bwd(FieldBwdArgs b) {
         NSR_TACC(0, tk0, tk1);
         const uint32_t m = tile * 16 + s;
         const bool valid = m < Mc;
+        // SORTED: the next tile's loads go out HERE, a whole iteration before they are consumed.  The lattice flushes issue
+        // their atomics inline, and one in-order vmcnt covers loads and atomics: a load can only be waited for together
+        // with everything issued before the wait -- so the wait at the loop top (for `cur`, issued an iteration ago) costs
+        // at most the trip of the last flush's atomics, and these loads have the MLP section and the scatter to land.
+        TileIn nxt_sorted = cur;
+        if (SORTED && tile + 1 < w_end) {
+            nxt_sorted = load_tile(tile + 1, idx_next);
+            if (tile + 2 < w_end) idx_next = fetch_idx(tile + 2);
+        }
         const float u0 = valid ? field_unit(cur.x0, a.bmin[0], a.bsize[0]) : 0.f;
         const float u1 = valid ? field_unit(cur.x1, a.bmin[1], a.bsize[1]) : 0.f;
         const float u2 = valid ? field_unit(cur.x2, a.bmin[2], a.bsize[2]) : 0.f;
@@ -774,6 +864,7 @@ k_field_bwd(FieldBwdArgs b) {
         // and the atomics issued ahead of them (vmcnt retires in order) have had the whole scatter to land.
         TileIn nxt = cur;
         if (!SORTED && tile + 1 < w_end) nxt = load_tile(tile + 1, fetch_idx(tile + 1));
+        if (SORTED) nxt = nxt_sorted;
         NSR_TICK(tk3);
         NSR_TACC(3, tk2, tk3);
         if (td || tc) {
@@ -783,14 +874,9 @@ k_field_bwd(FieldBwdArgs b) {
                 const int t = i >> 1, e0 = 2 * (i & 1);
                 sg[i] = live ? make_float4(gxd[t][e0], gxd[t][e0 + 1], gxc[t][e0], gxc[t][e0 + 1]) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
-            if (SORTED) field_scatter_lattice(latst, lds_lv, seqG, lat, b.grad_tables, u0, u1, u2, live, sg, lane, td, tc);
+            if (SORTED) field_scatter_lattice(latst, lat_key, lds_lv, seqG, lat, b.grad_tables, u0, u1, u2, live, sg, lane, td, tc,
+                                              lat_myS, lat_mybase);
             else field_scatter_seq(seq, lds_lv, seqG, q, gt1, live ? u0 : 0.f, live ? u1 : 0.f, live ? u2 : 0.f, sg, lane, td, tc);
-        }
-        if (SORTED && tile + 1 < w_end) {
-            // the lattice flushes issue their atomics inline, so the next tile's loads go out AFTER the scatter: a load
-            // issued before it could only be waited for together with every atomic behind it (one in-order vmcnt)
-            nxt = load_tile(tile + 1, idx_next);
-            if (tile + 2 < w_end) idx_next = fetch_idx(tile + 2);
         }
         NSR_TICK(tk4);
         NSR_TACC(2, tk3, tk4);
@@ -850,6 +936,9 @@ int nsr_field_backward(const nsr_field_desc *desc, const void *tables, const flo
     b.f.tables = tables; b.f.params = mlp_params; b.f.xyzs = xyzs; b.f.m_dev = m_dev; b.f.sigmas = nullptr; b.f.rgbs = nullptr;
     b.f.feats = const_cast<void *>(feats);
     b.f.perm = perm;
+    if (perm != nullptr) {
+        if (!lat_geometry(b.f.lv, b.lat)) return NSR_ERR_UNSUPPORTED;   // grid too fine for the 10-bit blocks: walk in buffer order
+    }
     if (feats && ((uintptr_t)feats & 15u)) return NSR_ERR_INVALID_ARG;
     b.grad_sigmas = grad_sigmas; b.grad_rgbs = grad_rgbs; b.grad_tables = grad_tables; b.grad_mlp = grad_mlp;
     b.train_density = train_density_table; b.train_color = train_color_table; b.nc = desc->num_classes;
