@@ -4,22 +4,29 @@
     python bench.py --gpus N --steps K --warmup W            (N == 1)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...  (N > 1)
 
-One "step" = one reconstruction-stage training step on one batch of synthetic LLFF 'room'-shaped
-rays per GPU (BASELINE.json configs[1]: LLFF 'room' reconstruction, full 1008x756 frames, HIP
-hash-encode + raymarch + fused MLP): device ray generation for `rays_per_gpu` pixels of a random
-training pose -> near/far -> occupancy-grid march + scan compaction -> fused field forward ->
-composite -> MSE + 0.001*CE loss (trainers/base.py:251-304) -> backward (composite bwd, fused field
-bwd with table scatter) -> [RCCL all-reduce of the gradient arena when N > 1] -> fused Adam+EMA.
-Nothing is skipped or cached inside the timed region; inputs (poses, bitfield, targets) are
-resident in HBM before it starts.
+Default workload = BASELINE.json configs[1]: LLFF 'room' reconstruction stage, full 1008x756 frames, one frame
+(762 048 rays) per step per GPU.  One "step" = device ray generation for the step's pixels of a training pose ->
+near/far -> [every 16 steps: device-side occupancy update, 4.19 M sigma queries] -> occupancy-grid march + scan
+compaction -> fused field forward -> composite -> MSE + 0.001*CE loss (trainers/base.py:251-304) [+ sparsity term,
+--sparsity-lambda, trainers/base.py:285-291,409-413] -> backward (composite bwd, fused field bwd with table scatter) ->
+[RCCL all-reduce of the gradient arena when N > 1] -> fused Adam + EMA.  Nothing is skipped or cached inside the timed
+region; inputs (poses, bitfield, targets) are resident in HBM before it starts.
 
-Prints ONE JSON line on rank 0 (contract in the task statement) including `roofline` for the
-dominant kernel (HIP-event timed on the launch stream inside the timed region) and `cpu_baseline`
-(the pure-PyTorch CPU port of the same render step, oracle/torch_port.py, on a bounded sample).
+Other workloads (BASELINE.json configs[2..4]):
+    --stage style                       configs[2]: one stylisation iteration per step (full-frame pass + VGG16/semantic-NNFM
+                                        loss in PyTorch + 24 deferred-backprop patches, colour table only), 1008x756
+    --scene fern --sparsity-lambda 0.01 configs[3]: fern cameras + the sparsity term (per-GPU part; the driver scales it out)
+    --compute-dtype bf16 --graph --rays-per-gpu 4096 | 40000
+                                        configs[4]: bf16 MLP + fp32 composite, render+loss+backward replayed as one hipGraph
+
+Prints ONE JSON line on rank 0 (contract in the task statement) including `roofline` for the dominant kernel and
+`cpu_baseline` (the pure-PyTorch CPU port of the same render step, oracle/torch_port.py, on a bounded sample).
+The GPU leg is printed to stderr as soon as it is done; the CPU leg runs after it, inside a hard time budget.
 """
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -30,12 +37,16 @@ if ROOT not in sys.path:
 import numpy as np
 import torch
 
+PROFILE_JSON = os.path.join(ROOT, 'profiles', 'r02_pmc_traffic.json')
+
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--stage', choices=['recon', 'style'], default='recon')
+    ap.add_argument('--scene', choices=['room', 'fern'], default='room')
     ap.add_argument('--rays-per-gpu', type=int, default=1008 * 756,
                     help='rays per step per GPU (weak scaling); default = every pixel of one 1008x756 frame. The reference '
                          'trains on 4096-ray batches (cfgs/training/default.yaml:1); large batches are the documented '
@@ -45,29 +56,38 @@ def parse():
     ap.add_argument('--table-dtype', choices=['f16', 'f32'], default='f16')
     ap.add_argument('--compute-dtype', choices=['f16', 'bf16'], default='f16')
     ap.add_argument('--samples-cap', type=int, default=160, help='sample-buffer capacity in samples per ray')
+    ap.add_argument('--sparsity-lambda', type=float, default=0.0, help='cfgs: --sparsity_lambda (0.01 in BASELINE configs[3])')
+    ap.add_argument('--no-occ-update', action='store_true', help='leave the periodic occupancy update out of the step')
+    ap.add_argument('--sort-samples', action='store_true', help='walk the field kernels in nsr_sample_order order')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--graph', action='store_true',
-                    help='replay the render+loss+backward part of the step as one captured hipGraph (no per-kernel '
-                         'event timing, so no roofline object): for the small-batch series')
-    ap.add_argument('--cpu-budget-s', type=float, default=20.0)
+                    help='replay the render+loss+backward part of the step as one captured hipGraph (small-batch series)')
+    ap.add_argument('--cpu-budget-s', type=float, default=12.0)
+    ap.add_argument('--max-steps', type=int, default=None, help='march steps per ray (1024; README stylisation command: 512)')
     ap.add_argument('--seed', type=int, default=69420)
     return ap.parse_args()
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# CPU baseline
+# ---------------------------------------------------------------------------------------------------------------------
 def cpu_baseline(budget_s, nc):
-    """The reference's pure-PyTorch path restated (oracle/torch_port.py): BASELINE config 1 shape
-    -- 200x200 patch rays of LLFF room frame 0, 64 samples/ray, fp32, forward + backward + SGD-free
-    gradient (no optimiser) -- on the host cores.  Bounded: runs whole 200x200 passes in 10k-ray
-    chunks until the budget is used; reports rays/s of the forward+backward pass."""
+    """The reference's pure-PyTorch path restated (oracle/torch_port.py) on BASELINE configs[0]'s shape -- rays of the
+    200x200 patch of LLFF room frame 0, 64 samples/ray, fp32 -- forward + backward, on the host cores.
+    SURVEY 8d: all host cores, 1 warm-up, median of >= 5 repetitions.  Bounded: a repetition is a slice of the 40 000
+    rays sized from a calibration chunk so that warm-up + 5 repetitions fit `budget_s`; the thread count is the one
+    that ran the calibration chunk faster (the 1-GPU box's cgroup gives 16 logical CPUs a fractional share, where one
+    thread can beat sixteen), and the line says which and why."""
     from oracle import oracle as O
     from oracle import torch_port as TP
-    from nerfstyle_amd.scene import load_room_cameras
-    poses, intr, _ = load_room_cameras(1)
+    from nerfstyle_amd.scene import load_cameras
+    t_start = time.perf_counter()
+    poses, intr, _ = load_cameras('room', 1)
     ro, rd = O.generate_rays(poses[0], intr.w, intr.h, intr.fx, intr.fy, intr.cx, intr.cy, 3, patch=(200, 0, 200, 200))
     field = TP.Field(num_classes=nc, sparse_grad=True)
 
-    def one(sl):
-        o, d = torch.tensor(ro[sl]), torch.tensor(rd[sl])
+    def one(lo, n):
+        o, d = torch.tensor(ro[lo:lo + n]), torch.tensor(rd[lo:lo + n])
         t0 = time.perf_counter()
         image, classes = TP.render_fixed_k(field, o, d, 0.2, 4.0, 64)
         t1 = time.perf_counter()
@@ -78,36 +98,90 @@ def cpu_baseline(budget_s, nc):
             p.grad = None
         return t1 - t0, t2 - t0
 
-    # thread count: all host cores unless the (cgroup-limited) box runs faster on one -- calibrated on
-    # a 250-ray chunk, the count actually used is what `cores` reports
-    best = None
     try:
-        ncpu = len(os.sched_getaffinity(0))
+        affinity = len(os.sched_getaffinity(0))
     except AttributeError:
-        ncpu = os.cpu_count() or 1
-    ncpu = max(1, min(ncpu, 16))      # the 1-GPU box's CPU share is 16 cores
-    for nt in sorted({ncpu, 1}, reverse=True):
+        affinity = os.cpu_count() or 1
+    cand = sorted({min(affinity, 16), 1}, reverse=True)
+    calib = {}
+    for nt in cand:
         torch.set_num_threads(nt)
-        one(slice(0, 250))
-        _, t = one(slice(250, 500))
-        if best is None or t < best[1]:
-            best = (nt, t)
-    torch.set_num_threads(best[0])
-    chunk = 500
-    done, t_used, t_fwd_only, i = 0, 0.0, None, 0
-    while t_used < budget_s and i < 200:
-        lo = (i * chunk) % 40000
-        tf, tt = one(slice(lo, lo + chunk))
-        done += chunk
-        t_used += tt
-        t_fwd_only = tf if t_fwd_only is None else min(t_fwd_only, tf)
-        i += 1
+        one(0, 100)
+        calib[nt] = one(100, 200)[1] / 200.0                 # seconds per ray, forward + backward
+    nt = min(calib, key=calib.get)
+    torch.set_num_threads(nt)
+    left = budget_s - (time.perf_counter() - t_start)
+    rep_rays = int(max(100, min(40000, left / 6.5 / calib[nt])))
+    reps, fwd = [], []
+    one(0, rep_rays)                                          # warm-up at the repetition size
+    for i in range(5):
+        lo = ((i + 1) * rep_rays) % max(1, 40000 - rep_rays)
+        tf, tt = one(lo, rep_rays)
+        reps.append(rep_rays / tt)
+        fwd.append(rep_rays / tf)
+        if time.perf_counter() - t_start > 2.0 * budget_s and len(reps) >= 3:     # hard stop: never run away
+            break
+    why = ('{} threads beat 1 thread on the calibration chunk ({:.0f} vs {:.0f} rays/s)'.format(nt, 1 / calib[nt], 1 / calib[1])
+           if nt != 1 else '1 thread beat {} threads on the calibration chunk ({:.0f} vs {:.0f} rays/s): the box gives its {} '
+           'logical CPUs a fractional cgroup share'.format(cand[0], 1 / calib[1], 1 / calib[cand[0]], affinity)) if len(cand) > 1 else 'one CPU'
     return {
-        'value': round(done / t_used / 1e6, 9), 'unit': 'Mrays/s', 'cores': int(torch.get_num_threads()), 'kind': 'port',
-        'sample': '{} rays of the 200x200 patch of LLFF room frame 0 x 64 samples/ray, fp32 pure-PyTorch port '
-                  '(oracle/torch_port.py), forward+backward, {:.1f} s; forward-only best {:.4f} Mrays/s'.format(
-                      done, t_used, chunk / t_fwd_only / 1e6),
+        'value': round(statistics.median(reps) / 1e6, 9), 'unit': 'Mrays/s', 'cores': int(nt), 'kind': 'port',
+        'sample': 'median of {} repetitions (1 warm-up) of {} rays of the 200x200 patch of LLFF room frame 0 x 64 samples/ray, '
+                  'fp32 pure-PyTorch port (oracle/torch_port.py), forward+backward; forward-only median {:.6f} Mrays/s; '
+                  'os.cpu_count()={}, affinity={}, threads used={} ({}); {:.1f} s'.format(
+                      len(reps), rep_rays, statistics.median(fwd) / 1e6, os.cpu_count(), affinity, nt, why,
+                      time.perf_counter() - t_start),
     }
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# common set-up
+# ---------------------------------------------------------------------------------------------------------------------
+def build(args, dev, rank):
+    from nerfstyle_amd import raymarching
+    from nerfstyle_amd.common import BBox
+    from nerfstyle_amd.config import NetworkConfig, RendererConfig
+    from nerfstyle_amd.renderer import Renderer
+    from nerfstyle_amd.scene import load_cameras, synthetic_density_grid
+    from nerfstyle_amd.style_nerf import StyleTCNerf
+    nc = args.num_classes
+    tdt = None if args.table_dtype == 'f16' else torch.float32
+    cdt = torch.float16 if args.compute_dtype == 'f16' else torch.bfloat16
+    # identical replicas on every rank: same seed for parameters and occupancy
+    model = StyleTCNerf(NetworkConfig(), BBox.from_radius(2.0), nc, enc_dtype=tdt, use_dir=False, compute_dtype=cdt)
+    poses_np, intr, _ = load_cameras(args.scene, args.res_scale)
+    rcfg = RendererConfig.llff()
+    if args.max_steps:
+        rcfg.max_steps = args.max_steps
+    r = Renderer(model, rcfg, intr, 2.0, raymarch_channels=3 + nc, samples_per_ray_cap=args.samples_cap).to(dev)
+    r.manual_seed(args.seed)
+    # Seeded synthetic occupancy: 28 boxes (seed 0) give ~64 emitted samples per ray on the room cameras.  The
+    # march reads THIS bitfield (a random-initialised model has no scene); the periodic occupancy update still runs at full
+    # cost from the model itself and maintains density_grid / density_bitfield / mean_density (Renderer.pin_march_bitfield).
+    grid = torch.tensor(synthetic_density_grid(2.0, 128, n_boxes=28, seed=0), device=dev)
+    scene_bits = raymarching.packbits(grid, 0.5)
+    if args.no_occ_update:
+        r.density_grid = grid
+        r.density_bitfield = scene_bits
+        r.update_occ = False
+    else:
+        r.pin_march_bitfield(scene_bits)
+        r.update_occ = True
+    r.sort_samples = bool(args.sort_samples)
+    return model, r, rcfg, torch.tensor(poses_np, device=dev), intr
+
+
+def profile_traffic(args):
+    """HBM traffic / atomic requests per sample from the committed PMC passes (profiles/): NOT measured in this run --
+    tagged as such, with the profile's commit and sample count so that a stale file is detectable."""
+    try:
+        with open(PROFILE_JSON) as f:
+            pm = json.load(f)
+    except (OSError, ValueError):
+        return None
+    if not (args.table_dtype == 'f16' and args.compute_dtype == 'f16' and args.stage == 'recon' and not args.sort_samples):
+        return None
+    return pm
 
 
 def main():
@@ -120,35 +194,33 @@ def main():
     assert torch.cuda.is_available(), 'bench.py needs a HIP device (no CPU fallback for the product path)'
     dev_index = int(os.environ.get('NSR_BENCH_DEVICE', local_rank))
     torch.cuda.set_device(dev_index)
-    rank, local_rank, world = P.init(backend)
+    rank, local_rank, world = P.init(backend, seed=args.seed)
     assert world == args.gpus, 'launch with torchrun --nproc-per-node {} (WORLD_SIZE={})'.format(args.gpus, world)
     dev = torch.device('cuda', dev_index)
+    if args.stage == 'style':
+        result = run_style(args, dev, rank, world)
+    else:
+        result = run_recon(args, dev, rank, world)
+    if rank == 0:
+        print('[bench] gpu leg done: ' + json.dumps(result), file=sys.stderr, flush=True)
+        if world == 1 and not args.no_cpu_baseline:
+            result['cpu_baseline'] = cpu_baseline(args.cpu_budget_s, args.num_classes)
+        print(json.dumps(result), flush=True)
+    P.barrier()
 
-    from nerfstyle_amd import profiling, raymarching
-    from nerfstyle_amd.common import BBox
-    from nerfstyle_amd.config import NetworkConfig, RendererConfig
+
+# ---------------------------------------------------------------------------------------------------------------------
+# reconstruction stage (configs[1], [3], [4])
+# ---------------------------------------------------------------------------------------------------------------------
+def run_recon(args, dev, rank, world):
+    from nerfstyle_amd import parallel as P
+    from nerfstyle_amd import profiling
     from nerfstyle_amd.optim import FusedAdam, exp_lr
-    from nerfstyle_amd.renderer import Renderer
-    from nerfstyle_amd.scene import load_room_cameras, synthetic_density_grid
-    from nerfstyle_amd.style_nerf import StyleTCNerf
-
+    model, r, rcfg, poses, intr = build(args, dev, rank)
     nc = args.num_classes
-    tdt = None if args.table_dtype == 'f16' else torch.float32
-    cdt = torch.float16 if args.compute_dtype == 'f16' else torch.bfloat16
-    # identical replicas on every rank: same seed for parameters and occupancy
-    model = StyleTCNerf(NetworkConfig(), BBox.from_radius(2.0), nc, enc_dtype=tdt, use_dir=False, compute_dtype=cdt)
-    poses_np, intr, _ = load_room_cameras(args.res_scale)
-    rcfg = RendererConfig.llff()
-    r = Renderer(model, rcfg, intr, 2.0, raymarch_channels=3 + nc, samples_per_ray_cap=args.samples_cap).to(dev)
-    # seeded synthetic occupancy: 28 boxes (seed 0) give 64.1 emitted samples per ray on the room cameras
-    grid = synthetic_density_grid(2.0, 128, n_boxes=28, seed=0)
-    r.density_grid = torch.tensor(grid, device=dev)
-    r.density_bitfield = raymarching.packbits(r.density_grid, 0.5)
-    r.update_occ = False
     # loss scaling as the reference's GradScaler (init scale 65536) when the MFMA chain is f16
     loss_scale = 65536.0 if args.compute_dtype == 'f16' else 1.0
     opt = FusedAdam(model, lr=1e-2, betas=(0.9, 0.999), eps=1e-15, ema_decay=0.95)
-    poses = torch.tensor(poses_np, device=dev)
     npix = intr.w * intr.h
     n_rays = min(args.rays_per_gpu, npix)
     gen = torch.Generator(device=dev)
@@ -160,6 +232,7 @@ def main():
     target_cls = torch.randint(0, nc, (npix,), device=dev, generator=tg)
     total_samples = torch.zeros(1, dtype=torch.int64, device=dev)
     overflow = torch.zeros(1, dtype=torch.int64, device=dev)
+    sp_lambda, sp_coeff, sp_n = args.sparsity_lambda, 0.05, 50000          # cfgs/training/default.yaml:17-19
 
     def loss_fn(out, pix):
         mse = torch.mean((out['rgb_map'] - target_rgb[pix]) ** 2)
@@ -167,10 +240,17 @@ def main():
         # gradient, without torch's one-block nll_loss reduction kernels (0.9 ms per 762 048-ray step)
         logits = out['classes']
         ce = (torch.logsumexp(logits, dim=1) - logits.gather(1, target_cls[pix][:, None])[:, 0]).mean() * 1e-3
-        return (mse + ce) * (loss_scale / world)
+        total = mse + ce
+        if sp_lambda > 0:
+            # trainers/base.py:409-413: sigma of 50 000 uniform points of the bbox, WITH autograd; :285-291: the loss
+            pts = torch.rand(sp_n, 3, device=dev, generator=gen) * 4.0 - 2.0
+            sig = model(pts)
+            total = total + torch.mean(torch.abs(1 - torch.exp(-sp_coeff * sig))) * sp_lambda
+        return total * (loss_scale / world)
 
     graphed = None
     if args.graph:
+        assert sp_lambda == 0, 'the sparsity term draws fresh points from a torch generator every step: not part of the captured step'
         from nerfstyle_amd.graph import GraphedRenderStep
         graphed = GraphedRenderStep(r, n_rays, loss_fn)
 
@@ -189,15 +269,177 @@ def main():
         opt.step(grad_scale=loss_scale)
         cnt = r._last_counter
         total_samples.add_(cnt[0].to(torch.int64))
-        overflow.add_((cnt[0] > r.sample_capacity(n_rays)).to(torch.int64))
+        overflow.add_((cnt[0] >= r.sample_capacity(n_rays)).to(torch.int64))
         return loss
 
     for it in range(args.warmup):
         step(it)
+    if args.sort_samples and args.warmup > 0:
+        # host estimate of the emitted count (read OUTSIDE the timed region) so the capacity buffer is not sorted whole
+        r.sort_prefix_hint = int(int(total_samples.item()) / args.warmup * 1.15)
     total_samples.zero_()
     overflow.zero_()
+    occ_before = int(r._occ_state[0]) if getattr(r, '_occ_state', None) is not None else 0
     profiling.reset()
     profiling.enabled = not args.graph      # event records cannot be captured into a graph
+    graph_ev = None
+    if args.graph:
+        graph_ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+    P.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    if graph_ev:
+        graph_ev[0].record()
+    for it in range(args.steps):
+        loss = step(args.warmup + it)
+    if graph_ev:
+        graph_ev[1].record()
+    torch.cuda.synchronize()
+    P.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    profiling.enabled = False
+    elapsed = P.max_over_ranks(elapsed, dev)
+    prof = profiling.summary()
+    if rank != 0:
+        return None
+
+    samples = int(total_samples.item())
+    spr = samples / max(args.steps * n_rays, 1)
+    value = world * n_rays * args.steps / elapsed / 1e6
+    occ_updates = (int(r._occ_state[0]) - occ_before) if getattr(r, '_occ_state', None) is not None else 0
+    tb = 2 if args.table_dtype == 'f16' else 4
+    # Algorithmic bytes per sample, SURVEY 8d: forward gather = 2 enc x 16 lvl x 8 corners x 2 feat x tb = 512 x tb;
+    # backward = the gather-side read-modify-write of the same 256 entries = 2 x the forward bytes.
+    bytes_per_sample = {'field_fwd': 512 * tb, 'field_bwd': 2 * 512 * tb}
+    pm = profile_traffic(args)
+
+    def roof(name, launches, avg_ms):
+        per_launch = bytes_per_sample[name] * samples / max(launches, 1)
+        ach = per_launch / (avg_ms * 1e-3) / 1e9
+        d = {'bound': 'hbm', 'kernel': 'k_' + name, 'achieved': round(ach, 1), 'peak': 8000.0, 'unit': 'GB/s',
+             'frac': round(ach / 8000.0, 4), 'traffic': None, 'avg_launch_ms': round(avg_ms, 4),
+             'algorithmic_bytes_per_sample': bytes_per_sample[name], 'samples_per_launch': int(samples / max(launches, 1))}
+        k = pm['kernels'].get('k_' + name) if pm else None
+        if k:
+            d['traffic'] = int(k['traffic_bytes_per_sample'] * samples / max(launches, 1))
+            d['traffic_source'] = ('NOT measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command in '
+                                   'profiles/{} (per-sample figure x this run\'s samples per launch)'.format(os.path.basename(PROFILE_JSON)))
+            d['profile_commit'] = pm.get('commit')
+            d['profile_samples_per_launch'] = pm.get('samples_per_launch')
+        return d
+
+    roofline, extra = None, {}
+    if prof:
+        dom = max(prof.items(), key=lambda kv: kv[1][1])[0]
+        if dom in bytes_per_sample:
+            roofline = roof(dom, prof[dom][0], prof[dom][2])
+        if 'field_fwd' in prof:
+            launches, tot_ms, avg_ms = prof['field_fwd']
+            extra['hash_gather_fwd'] = roof('field_fwd', launches, avg_ms)
+            flops = 2.0 * (12544 + 64 * nc) * samples / max(launches, 1)      # SURVEY 8d, no padding counted
+            tf = flops / (avg_ms * 1e-3) / 1e12
+            extra['mlp_mfma_fwd'] = {'bound': 'mfma', 'kernel': 'k_field_fwd', 'achieved': round(tf, 1), 'peak': 2500.0,
+                                     'unit': 'TFLOP/s', 'frac': round(tf / 2500.0, 4),
+                                     'note': 'MLP FLOPs of the fused kernel over its whole duration (gather-bound kernel)'}
+        k = pm['kernels'].get('k_field_bwd') if pm else None
+        if 'field_bwd' in prof and k and k.get('atomic_requests_per_sample'):
+            # what k_field_bwd actually queues on: memory-side float-atomic requests (TCC_EA0_ATOMIC per sample from the PMC
+            # pass in profiles/) against the chip-wide rate tools/atomic_footprint_bench.hip measures
+            launches, tot_ms, avg_ms = prof['field_bwd']
+            rate = k['atomic_requests_per_sample'] * samples / max(launches, 1) / (avg_ms * 1e-3) / 1e9
+            extra['atomic_requests_bwd'] = {'bound': 'memory-side atomic unit', 'kernel': 'k_field_bwd', 'achieved': round(rate, 2),
+                                            'peak': 21.06, 'unit': 'G requests/s', 'frac': round(rate / 21.06, 4),
+                                            'requests_per_sample': k['atomic_requests_per_sample'],
+                                            'source': 'requests/sample from profiles/ (not this run); peak = measured microbenchmark'}
+    elif graph_ev:
+        # whole-replay timing: the kernels cannot be event-timed inside a graph; the per-kernel split of this
+        # configuration is in profiles/ (rocprofv3 --kernel-trace of the same command)
+        ms = graph_ev[0].elapsed_time(graph_ev[1]) / args.steps
+        per_step = (bytes_per_sample['field_fwd'] + bytes_per_sample['field_bwd']) * samples / args.steps
+        ach = per_step / (ms * 1e-3) / 1e9
+        roofline = {'bound': 'hbm', 'kernel': 'whole captured step (graph replay + fused Adam), k_field_fwd + k_field_bwd bytes',
+                    'achieved': round(ach, 1), 'peak': 8000.0, 'unit': 'GB/s', 'frac': round(ach / 8000.0, 4), 'traffic': None,
+                    'avg_launch_ms': round(ms, 4), 'algorithmic_bytes_per_sample': bytes_per_sample['field_fwd'] + bytes_per_sample['field_bwd'],
+                    'samples_per_launch': int(samples / args.steps),
+                    'note': 'small-batch steps are launch/latency-bound, not bandwidth-bound; per-kernel split in profiles/'}
+    wl = "LLFF '{}' reconstruction stage, {}x{} frames, {} rays/step/GPU, synthetic occupancy (28 seeded boxes), {:.1f} samples/ray".format(
+        args.scene, intr.w, intr.h, n_rays, spr)
+    if sp_lambda > 0:
+        wl += ', --sparsity_lambda {} (50 000 sigma-only points per step, with gradient)'.format(sp_lambda)
+    if args.graph:
+        wl += ', render+loss+backward replayed as one hipGraph'
+    return {
+        'metric': 'train Mrays/sec', 'value': round(value, 4), 'unit': 'Mrays/s', 'n_gpus': world, 'steps': args.steps,
+        'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True,
+        'scaling': 'weak', 'vs_baseline': None, 'dtype': args.compute_dtype, 'data': 'synthetic',
+        'config': {
+            'workload': wl, 'rays_per_step_per_gpu': n_rays, 'samples_per_ray': round(spr, 2), 'max_steps': rcfg.max_steps,
+            'num_classes': nc, 'table_dtype': args.table_dtype, 'mfma_dtype': args.compute_dtype,
+            'params': int(model.arena.numel()), 'parallelism': 'rays sharded x{} + RCCL all-reduce'.format(world),
+            'occupancy_updates_in_timed_region': occ_updates,
+            'occupancy': ('device-side update every {} steps inside the step (full update: {} sigma queries); the march reads the seeded '
+                          'synthetic bitfield (random-init model has no scene)'.format(rcfg.update_iter, r.cascade * rcfg.grid_size ** 3)
+                          if not args.no_occ_update else 'fixed synthetic bitfield, no update'),
+            'sample_order': 'nsr_sample_order (Morton blocks)' if args.sort_samples else 'ray order',
+            'sample_capacity_overflows': int(overflow.item()), 'final_loss': float(loss.detach()) / loss_scale * world,
+        },
+        'kernel_ms_per_step': {k: round(v[1] / args.steps, 4) for k, v in sorted(prof.items())},
+        'roofline': roofline,
+        'rooflines_other': extra,
+    }
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# stylisation stage (configs[2])
+# ---------------------------------------------------------------------------------------------------------------------
+def run_style(args, dev, rank, world):
+    """One step = one StyleTrainer.run_iter (trainers/style.py:162-204) on a 1008x756 frame: full-frame pass without autograd,
+    VGG16 relu3 content + SemanticStyleLoss (PyTorch, MIOpen convolutions), d loss / d pixels, 24 patch re-renders of
+    200x200 with autograd (sharded over ranks), colour-table-only fused Adam (style.py:25), lr 0.1 (cfgs/training/style.yaml)."""
+    from nerfstyle_amd import parallel as P
+    from nerfstyle_amd import profiling
+    from nerfstyle_amd.losses import SemanticStyleLoss
+    from nerfstyle_amd.optim import FusedAdam
+    from nerfstyle_amd.stylize import StyleCriterion, deferred_backprop_step, patch_list
+    from nerfstyle_amd.vgg import VGG16FeatureExtractor
+    if args.max_steps is None:
+        args.max_steps = 512                                  # README stylisation command: --max_steps 512
+    args.no_occ_update = True                                 # StyleTrainer loads a trained model; its run_iter never calls update_state
+    model, r, rcfg, poses, intr = build(args, dev, rank)
+    nc = args.num_classes
+    W, H = intr.size()
+    g = torch.Generator(device=dev)
+    g.manual_seed(args.seed)
+    targets = {}
+    style = torch.rand(3, H, W, device=dev, generator=g)                       # SingleImage(longer edge = max(W, H)), style.py:60-61
+    seg = torch.randint(0, nc, (H, W), device=dev, generator=g)
+    fx = VGG16FeatureExtractor(['relu3']).to(dev)
+    crit = StyleCriterion(fx, SemanticStyleLoss(['relu3'], clusters=seg), content_lambda=0.001, style_lambda=1.0)
+    crit.init_style(style, num_classes=nc)
+    opt = FusedAdam(model, lr=0.1, keywords=['x_color_embedder'])
+    loss_scale = 65536.0 if args.compute_dtype == 'f16' else 1.0
+    n_patches = len(patch_list(W, H, 200))
+    total_samples = torch.zeros(1, dtype=torch.int64, device=dev)
+
+    def step(it):
+        frame = (it * 7) % poses.shape[0]                                       # every rank works on the SAME frame
+        if frame not in targets:
+            tg = torch.Generator(device=dev)
+            tg.manual_seed(args.seed + frame)
+            targets[frame] = torch.rand(3, H, W, device=dev, generator=tg)
+
+        def image_loss(rgb, classes):
+            return crit(rgb, targets[frame], classes, frame_key=frame, it=it)[0]
+        loss, _ = deferred_backprop_step(r, poses[frame], image_loss, patch_size=200, loss_scale=loss_scale, rank=rank, world=world,
+                                         with_classes=True)
+        opt.step(grad_scale=loss_scale)
+        return loss
+
+    for it in range(args.warmup):
+        step(it)
+    profiling.reset()
+    profiling.enabled = True
     P.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -210,83 +452,36 @@ def main():
     profiling.enabled = False
     elapsed = P.max_over_ranks(elapsed, dev)
     prof = profiling.summary()
-
-    if rank == 0:
-        samples = int(total_samples.item())
-        spr = samples / max(args.steps * n_rays, 1)
-        value = world * n_rays * args.steps / elapsed / 1e6
-        # ---- roofline of the dominant kernel ------------------------------------------------
-        dom = max(prof.items(), key=lambda kv: kv[1][1])[0] if prof else None
-        tb = 2 if args.table_dtype == 'f16' else 4
-        # algorithmic bytes per sample (SURVEY 8d / DESIGN.md): forward gather = 2 enc x 16 lvl x 8 corners x
-        # 2 feat x tb = 512 x tb; backward = read-modify-write of the same 512 fp32 gradient elements
-        # (2 x 2048 B) + either the 128 B of encoded features the forward saved or the gather again
-        saved = bool(getattr(model, 'save_features', False))
-        bytes_per_sample = {'field_fwd': 512 * tb, 'field_bwd': 2 * 512 * 4 + (128 if saved else 512 * tb)}
-        roofline = None
-        # HBM traffic per launch from the PMC passes of profiles/ (separate rocprofv3 --pmc FETCH_SIZE /
-        # --pmc WRITE_SIZE runs of this same command, corrected as MI355X_MICROARCH.md prescribes);
-        # scaled by the sample count of this run, null when the profile does not match the configuration
-        traffic_per_sample = {}
-        atomic_req_per_sample = None
-        try:
-            with open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')) as f:
-                pm = json.load(f)
-            if args.table_dtype == 'f16' and args.compute_dtype == 'f16':
-                traffic_per_sample = {k[2:]: v['traffic_bytes_per_sample'] for k, v in pm['kernels'].items()}
-                atomic_req_per_sample = pm['kernels'].get('k_field_bwd', {}).get('atomic_requests_per_sample')
-        except (OSError, KeyError, ValueError):
-            pass
-
-        def roof(name):
-            launches, tot_ms, avg_ms = prof[name]
-            per_launch = bytes_per_sample[name] * samples / max(launches, 1)
-            ach = per_launch / (avg_ms * 1e-3) / 1e9
-            tr = traffic_per_sample.get(name)
-            return {'bound': 'hbm', 'kernel': 'k_' + name, 'achieved': round(ach, 1), 'peak': 8000.0, 'unit': 'GB/s',
-                    'frac': round(ach / 8000.0, 4),
-                    'traffic': None if tr is None else int(tr * samples / max(launches, 1)),
-                    'avg_launch_ms': round(avg_ms, 4), 'algorithmic_bytes_per_sample': bytes_per_sample[name]}
-        if dom in bytes_per_sample:
-            roofline = roof(dom)
-        extra = {}
-        if 'field_fwd' in prof:
-            extra['hash_gather_fwd'] = roof('field_fwd')
-            launches, tot_ms, avg_ms = prof['field_fwd']
-            flops = 2.0 * (12544 + 64 * nc) * samples / max(launches, 1)      # SURVEY 8d, no padding counted
-            tf = flops / (avg_ms * 1e-3) / 1e12
-            extra['mlp_mfma_fwd'] = {'bound': 'mfma', 'kernel': 'k_field_fwd', 'achieved': round(tf, 1), 'peak': 2500.0,
-                                     'unit': 'TFLOP/s', 'frac': round(tf / 2500.0, 4),
-                                     'note': 'MLP FLOPs of the fused kernel over its whole duration (gather-bound kernel)'}
-        if 'field_bwd' in prof and atomic_req_per_sample:
-            # the resource k_field_bwd actually saturates: memory-side float-atomic requests (TCC_EA0_ATOMIC per sample
-            # from the PMC pass in profiles/) against the chip-wide rate tools/atomic_footprint_bench.hip measures
-            launches, tot_ms, avg_ms = prof['field_bwd']
-            rate = atomic_req_per_sample * samples / max(launches, 1) / (avg_ms * 1e-3) / 1e9
-            extra['atomic_requests_bwd'] = {'bound': 'memory-side atomic unit', 'kernel': 'k_field_bwd', 'achieved': round(rate, 2),
-                                            'peak': 21.06, 'unit': 'G requests/s', 'frac': round(rate / 21.06, 4),
-                                            'requests_per_sample': atomic_req_per_sample}
-        result = {
-            'metric': 'train Mrays/sec', 'value': round(value, 4), 'unit': 'Mrays/s', 'n_gpus': world, 'steps': args.steps,
-            'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': args.compute_dtype, 'data': 'synthetic',
-            'config': {
-                'workload': "LLFF 'room' reconstruction stage, {}x{} frames, {} rays/step/GPU, synthetic occupancy "
-                            '(28 seeded boxes), {:.1f} samples/ray'.format(intr.w, intr.h, n_rays, spr),
-                'rays_per_step_per_gpu': n_rays, 'samples_per_ray': round(spr, 2), 'max_steps': rcfg.max_steps,
-                'num_classes': nc, 'table_dtype': args.table_dtype, 'mfma_dtype': args.compute_dtype,
-                'params': int(model.arena.numel()), 'parallelism': 'rays sharded x{} + RCCL all-reduce'.format(world),
-                'sample_capacity_overflows': int(overflow.item()), 'final_loss': float(loss.detach()) / loss_scale * world,
-            },
-            'kernel_ms_per_step': {k: round(v[1] / args.steps, 4) for k, v in sorted(prof.items())},
-            'roofline': roofline,
-            'rooflines_other': extra,
-        }
-        print('[bench] gpu leg done: ' + json.dumps(result), file=sys.stderr, flush=True)
-        if world == 1 and not args.no_cpu_baseline:
-            result['cpu_baseline'] = cpu_baseline(args.cpu_budget_s, nc)
-        print(json.dumps(result), flush=True)
-    P.barrier()
+    if rank != 0:
+        return None
+    # rays whose forward+backward completed: the frame's pixels once per iteration (pass 2 covers every pixel once with
+    # autograd; the no-grad pass 1 is overhead of the method, not counted as extra rays)
+    value = W * H * args.steps / elapsed / 1e6
+    tb = 2 if args.table_dtype == 'f16' else 4
+    roofline = None
+    if 'field_bwd' in prof:
+        launches, tot_ms, avg_ms = prof['field_bwd']
+        roofline = {'bound': 'hbm', 'kernel': 'k_field_bwd (colour table only)', 'achieved': None, 'peak': 8000.0, 'unit': 'GB/s',
+                    'frac': None, 'traffic': None, 'avg_launch_ms': round(avg_ms, 4), 'launches_per_step': launches / args.steps,
+                    'algorithmic_bytes_per_sample': 512 * tb,
+                    'note': 'per-launch sample counts stay on the device in this mode; see kernel_ms_per_step and profiles/'}
+    return {
+        'metric': 'train Mrays/sec', 'value': round(value, 4), 'unit': 'Mrays/s', 'n_gpus': world, 'steps': args.steps,
+        'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True,
+        'scaling': 'strong', 'vs_baseline': None, 'dtype': args.compute_dtype, 'data': 'synthetic',
+        'config': {
+            'workload': "LLFF '{}' stylisation stage, {}x{} frame per iteration: 1 full-frame no-grad pass + VGG16-relu3 content / "
+                        "semantic-NNFM loss (PyTorch) + {} deferred-backprop patches of 200x200, colour table only, max_steps {}; random "
+                        "seeded VGG weights, style image and segment maps (none exist offline)".format(args.scene, W, H, n_patches, rcfg.max_steps),
+            'rays_per_step': W * H, 'patches': n_patches, 'max_steps': rcfg.max_steps, 'num_classes': nc,
+            'table_dtype': args.table_dtype, 'mfma_dtype': args.compute_dtype,
+            'parallelism': 'patches + pass-1 pixel rows sharded x{}, packed colour-table gradient all-reduce'.format(world),
+            'final_loss': float(loss) , 'matching': crit.style_loss.matching,
+        },
+        'kernel_ms_per_step': {k: round(v[1] / args.steps, 4) for k, v in sorted(prof.items())},
+        'roofline': roofline,
+        'rooflines_other': {},
+    }
 
 
 if __name__ == '__main__':

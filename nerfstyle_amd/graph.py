@@ -24,7 +24,10 @@ class GraphedRenderStep:
 
     def __init__(self, renderer: Renderer, n_rays: int, loss_fn: Callable[[Dict[str, torch.Tensor], torch.Tensor], torch.Tensor],
                  warmup: int = 2):
-        assert not renderer.update_occ, 'occupancy updates run on their own schedule: call update_state() between replays'
+        # Occupancy updates keep their schedule (every cfg.update_iter steps, renderer.py:206-207) but run BETWEEN replays:
+        # the full / partial update have different launch shapes, and the per-step counter ring of the eager path
+        # changes its pointer every step.  The device-side update (nsr_occ_*) needs no host read, so it costs no bubble.
+        self.occ_updates = bool(renderer.update_occ)
         self.r = renderer
         dev = renderer.device
         self.pose = torch.zeros(4, 4, dtype=torch.float32, device=dev)
@@ -36,7 +39,12 @@ class GraphedRenderStep:
         self._warmup = warmup
 
     def _body(self):
-        out = self.r.render(self.pose, None, training=True, pix_subset=self.pix)
+        keep = self.r.update_occ
+        self.r.update_occ = False          # inside the graph: fixed launch sequence, a private device-side counter
+        try:
+            out = self.r.render(self.pose, None, training=True, pix_subset=self.pix)
+        finally:
+            self.r.update_occ = keep
         loss = self.loss_fn(out, self.pix)
         loss.backward()
         return loss.detach()
@@ -46,6 +54,10 @@ class GraphedRenderStep:
         self.pix.copy_(pix)
         model = self.r.model
         model._ensure_grad()
+        # the f16 gather copy must be current BEFORE capture: a captured replay reads the copy the optimiser keeps in sync
+        # (FusedAdam refreshes it in its own pass) and must not bake a cast of stale data into the graph
+        if model.table_dtype == torch.float16:
+            model._gather_tables()
         # warm-up on a side stream (allocator pools, lazy initialisation), as torch.cuda.graphs asks
         s = torch.cuda.Stream(device=self.r.device)
         s.wait_stream(torch.cuda.current_stream())
@@ -64,6 +76,16 @@ class GraphedRenderStep:
     def __call__(self, pose: torch.Tensor, pix: torch.Tensor) -> torch.Tensor:
         if self.graph is None:
             self.capture(pose, pix)
+        r = self.r
+        if self.occ_updates:
+            if r.local_step % r.cfg.update_iter == 0:
+                r.update_state()
+            r.local_step += 1
+        m = r.model
+        if m.table_dtype == torch.float16 and m._half_version != m.arena._version:
+            # parameters changed by something other than FusedAdam (load_state_dict, an EMA swap, a stock optimiser):
+            # refresh the f16 gather copy the captured kernels read
+            m._gather_tables()
         self.pose.copy_(pose)
         self.pix.copy_(pix)
         self.graph.replay()

@@ -44,6 +44,7 @@ class Renderer(torch.nn.Module):
         # workload: forward 8.3 -> 8.2 ms, backward 49.3 -> 48.4 ms, sort 1.8 ms -- no net gain yet.
         self.sort_samples = False
         self.sort_prefix_hint = None     # estimate of the emitted sample count (host int) so a capacity buffer is not sorted whole
+        self._pinned_bitfield = None
         self.aabb = torch.tensor([-bound, -bound, -bound, bound, bound, bound], dtype=torch.float32)
         self.cascade = 1 + ceil(log2(bound))
         grid_size = self.cfg.grid_size
@@ -175,6 +176,18 @@ class Renderer(torch.nn.Module):
                                        L.p(ws), L.stream()), 'occ_update')
         self._mean_count_stale = True
 
+    def pin_march_bitfield(self, bitfield: Optional[torch.Tensor]):
+        """Benchmark / debugging hook: march through THIS bitfield while update_state keeps maintaining density_grid,
+        mean_density and density_bitfield from the model as usual (None: back to density_bitfield).  Synthetic
+        throughput runs use it: a random-initialised model has no scene, so the seeded synthetic occupancy stands in for
+        the converged one while the periodic update still runs at full cost inside the step."""
+        self._pinned_bitfield = bitfield
+        return self
+
+    @property
+    def march_bitfield(self):
+        return self.density_bitfield if self._pinned_bitfield is None else self._pinned_bitfield
+
     # ---- training render -----------------------------------------------------------------------
     def sample_capacity(self, n_rays: int) -> int:
         per_ray = self.cfg.max_steps if self.samples_per_ray_cap is None else min(self.samples_per_ray_cap,
@@ -198,7 +211,7 @@ class Renderer(torch.nn.Module):
         M = self.sample_capacity(N)
         self._last_capacity = M
         xyzs, _, deltas, rays_info = raymarching.march_rays_train_nosync(
-            rays.origins, rays.dirs, self.bound, self.density_bitfield, self.cascade, self.cfg.grid_size, nears, fars,
+            rays.origins, rays.dirs, self.bound, self.march_bitfield, self.cascade, self.cfg.grid_size, nears, fars,
             M, counter, 0., self.cfg.max_steps)
         perm = self.model.sample_order(xyzs, counter, self.sort_prefix_hint) if self.sort_samples else None
         sigmas, rgbs = self.model.field(xyzs, sigma_only=False, m_dev=counter, density_scale=self.cfg.density_scale, perm=perm)
@@ -230,7 +243,7 @@ class Renderer(torch.nn.Module):
         M = self.sample_capacity(N)
         counter = torch.zeros(2, dtype=torch.int32, device=self.device)
         xyzs, _, deltas, rays_info = raymarching.march_rays_train_nosync(
-            rays.origins, rays.dirs, self.bound, self.density_bitfield, self.cascade, self.cfg.grid_size, nears, fars,
+            rays.origins, rays.dirs, self.bound, self.march_bitfield, self.cascade, self.cfg.grid_size, nears, fars,
             M, counter, 0., self.cfg.max_steps)
         if self.samples_per_ray_cap is not None and self.samples_per_ray_cap < self.cfg.max_steps:
             # a bounded buffer can overflow, and the march then DROPS the rays that do not fit (raymarching.cu:517);
@@ -273,7 +286,7 @@ class Renderer(torch.nn.Module):
                 break
             n_step = max(min(N // n_alive, 8), 1)
             xyzs, _, deltas = raymarching.march_rays(
-                n_alive, n_step, rays_alive, rays_t, rays.origins, rays.dirs, None, self.bound, self.density_bitfield,
+                n_alive, n_step, rays_alive, rays_t, rays.origins, rays.dirs, None, self.bound, self.march_bitfield,
                 self.cascade, self.cfg.grid_size, nears, fars, 128, False, 0., self.cfg.max_steps, self.cfg.use_ndc)
             sigmas, rgbs = self.model.field(xyzs, sigma_only=False, density_scale=self.cfg.density_scale)
             raymarching.composite_rays(n_alive, n_step, rays_alive, rays_t, sigmas, rgbs, deltas, self.cfg.use_ndc,

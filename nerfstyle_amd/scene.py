@@ -12,15 +12,20 @@ from .common import Intrinsics
 _ASSETS = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'assets')
 
 
-def load_room_cameras(scale_res: int = 1):
-    """-> (poses float32 [35,4,4] with the dataset's 0.33 translation scale applied, Intrinsics,
-    meta dict).  scale_res=2 gives BASELINE config 2's 1008x756 frames."""
-    with open(os.path.join(_ASSETS, 'llff_room_cameras.json')) as f:
+def load_cameras(scene: str = 'room', scale_res: int = 1):
+    """-> (poses float32 [F,4,4] with the dataset's 0.33 translation scale applied, Intrinsics, meta dict) of the LLFF
+    scene `scene` ('room': 35 training frames, 'fern': 17; the reference's transforms_train.json, a data file).
+    scale_res=2 gives the 1008x756 frames of BASELINE config 2."""
+    with open(os.path.join(_ASSETS, 'llff_{}_cameras.json'.format(scene))) as f:
         c = json.load(f)
     poses = np.asarray(c['poses'], dtype=np.float32)
     intr = Intrinsics(h=c['h'] * scale_res, w=c['w'] * scale_res, fx=c['fl_x'] * scale_res, fy=c['fl_y'] * scale_res,
                       cx=c['cx'] * scale_res, cy=c['cy'] * scale_res)
     return poses, intr, c
+
+
+def load_room_cameras(scale_res: int = 1):
+    return load_cameras('room', scale_res)
 
 
 def _expand_bits(v):

@@ -15,12 +15,46 @@ Multi-GPU: patches are independent units, so pass 2 shards the patch list across
 pixel rows (all-gathered, <= 9.1 MB for 1008x756); the colour-table gradient is all-reduced with the
 rest of the arena by parallel.sync_gradients.
 """
-from typing import Callable, List
+from typing import Callable, List, Optional
 
 import torch
+import torch.nn.functional as F
 
 from . import parallel as P
 from .common import Box2D
+
+
+class StyleCriterion:
+    """The image-space loss of StyleTrainer.calc_loss (trainers/style.py:70-105): VGG16 'relu3' features of the rendered
+    frame, the ground-truth frame and the style image; content = MSE(rendered, ground-truth features) * content_lambda,
+    style = SemanticStyleLoss(rendered features | class predictions) * style_lambda (cfgs/training/style.yaml:
+    content_lambda 0.001, style_lambda 1.0).  The features of the fixed images are computed once and cached (the
+    reference re-extracts target and style features every iteration, style.py:88-89)."""
+
+    def __init__(self, fx, style_loss, content_lambda: float = 0.001, style_lambda: float = 1.0, content_feat: str = 'relu3'):
+        self.fx, self.style_loss = fx, style_loss
+        self.content_lambda, self.style_lambda, self.content_feat = content_lambda, style_lambda, content_feat
+        self._target_feats = {}
+
+    @torch.no_grad()
+    def init_style(self, style_image: torch.Tensor, num_classes: int):
+        """style_image [3,H,W] in [0,1] (trainers/style.py:66-68)"""
+        self.style_loss.init_feats(self.fx(style_image), num_classes=num_classes)
+
+    @torch.no_grad()
+    def target_features(self, key, target_chw: torch.Tensor):
+        if key not in self._target_feats:
+            self._target_feats[key] = self.fx(target_chw)[self.content_feat]
+        return self._target_feats[key]
+
+    def __call__(self, rgb_hw3: torch.Tensor, target_chw: torch.Tensor, classes_hwc: torch.Tensor, frame_key=None, it: int = 0):
+        """rgb_hw3 [H,W,3] (requires_grad), target_chw [3,H,W], classes_hwc [H,W,nc] logits -> (total, content, style)"""
+        rgb_feats = self.fx(rgb_hw3.permute(2, 0, 1))
+        tgt = self.target_features(frame_key, target_chw) if frame_key is not None else self.fx(target_chw)[self.content_feat]
+        preds = torch.argmax(classes_hwc, dim=-1)                                   # style.py:85
+        content = F.mse_loss(rgb_feats[self.content_feat], tgt) * self.content_lambda
+        style = self.style_loss(rgb_feats, None, preds, it) * self.style_lambda
+        return content + style, content.detach(), style.detach()
 
 
 def patch_list(w: int, h: int, patch: int) -> List[Box2D]:
@@ -33,24 +67,34 @@ def patch_list(w: int, h: int, patch: int) -> List[Box2D]:
 
 
 @torch.no_grad()
-def render_full_frame(renderer, pose, rank: int = 0, world: int = 1):
-    """Pass 1.  Returns rgb_map [H, W, 3] (identical on every rank)."""
+def render_full_frame(renderer, pose, rank: int = 0, world: int = 1, with_classes: bool = False):
+    """Pass 1.  Returns rgb_map [H, W, 3] (identical on every rank); with_classes: (rgb_map, classes [H, W, nc])."""
     W, H = renderer.intr.size()
+    C = renderer.raymarch_channels
     if world == 1:
         out = renderer.render(pose, None, training=True)
-        return out['rgb_map'].view(H, W, 3)
-    y0, y1 = P.shard_bounds(H, rank, world)
-    part = renderer.render(pose, None, patch=Box2D(0, y0, W, y1 - y0), training=True)['rgb_map'] if y1 > y0 else \
-        torch.empty(0, 3, device=renderer.device)
-    sizes = [(P.shard_bounds(H, r, world)[1] - P.shard_bounds(H, r, world)[0]) * W for r in range(world)]
-    chunks = [torch.empty(n, 3, device=renderer.device) for n in sizes]
-    torch.distributed.all_gather(chunks, part.contiguous()) if len(set(sizes)) == 1 else _all_gather_ragged(chunks, part)
-    return torch.cat(chunks, 0).view(H, W, 3)
+        full = torch.cat((out['rgb_map'], out['classes']), dim=1)
+    else:
+        y0, y1 = P.shard_bounds(H, rank, world)
+        if y1 > y0:
+            o = renderer.render(pose, None, patch=Box2D(0, y0, W, y1 - y0), training=True)
+            part = torch.cat((o['rgb_map'], o['classes']), dim=1)
+        else:
+            part = torch.empty(0, C, device=renderer.device)
+        sizes = [(P.shard_bounds(H, r, world)[1] - P.shard_bounds(H, r, world)[0]) * W for r in range(world)]
+        chunks = [torch.empty(n, C, device=renderer.device) for n in sizes]
+        if len(set(sizes)) == 1:
+            torch.distributed.all_gather(chunks, part.contiguous())
+        else:
+            _all_gather_ragged(chunks, part)
+        full = torch.cat(chunks, 0)
+    rgb = full[:, :3].reshape(H, W, 3)
+    return (rgb, full[:, 3:].reshape(H, W, C - 3)) if with_classes else rgb
 
 
 def _all_gather_ragged(chunks, part):
     n = max(c.shape[0] for c in chunks)
-    pad = torch.zeros(n, 3, device=part.device)
+    pad = torch.zeros(n, part.shape[1], device=part.device)
     pad[:part.shape[0]] = part
     bufs = [torch.empty_like(pad) for _ in chunks]
     torch.distributed.all_gather(bufs, pad)
@@ -58,14 +102,19 @@ def _all_gather_ragged(chunks, part):
         c.copy_(b[:c.shape[0]])
 
 
-def deferred_backprop_step(renderer, pose, image_loss: Callable[[torch.Tensor], torch.Tensor], patch_size: int = 200,
-                           loss_scale: float = 1.0, rank: int = 0, world: int = 1, only_color_table: bool = True):
-    """One stylisation iteration up to (not including) the optimiser step.  `image_loss` maps
-    rgb [H, W, 3] (requires_grad) to a scalar.  Gradients accumulate into model.arena.grad.
-    Returns (loss value, rgb_map of pass 1)."""
+def deferred_backprop_step(renderer, pose, image_loss: Callable, patch_size: int = 200, loss_scale: float = 1.0, rank: int = 0,
+                           world: int = 1, only_color_table: bool = True, with_classes: bool = False):
+    """One stylisation iteration up to (not including) the optimiser step.  `image_loss` maps rgb [H, W, 3]
+    (requires_grad) -- and, with_classes, the class logits [H, W, nc] of the same pass -- to a scalar.
+    Gradients accumulate into model.arena.grad.  Returns (loss value, rgb_map of pass 1)."""
     W, H = renderer.intr.size()
-    rgb = render_full_frame(renderer, pose, rank, world).detach().requires_grad_(True)
-    loss = image_loss(rgb)
+    if with_classes:
+        rgb, classes = render_full_frame(renderer, pose, rank, world, with_classes=True)
+        rgb = rgb.detach().requires_grad_(True)
+        loss = image_loss(rgb, classes.detach())
+    else:
+        rgb = render_full_frame(renderer, pose, rank, world).detach().requires_grad_(True)
+        loss = image_loss(rgb)
     (loss * loss_scale).backward()
     grad_map = rgb.grad                                   # [H, W, 3]  (style.py:187)
     patches = patch_list(W, H, patch_size)

@@ -64,6 +64,19 @@ def main():
     os.makedirs(os.path.join(REPO, 'nerfstyle_amd', 'assets'), exist_ok=True)
     with open(os.path.join(REPO, 'nerfstyle_amd', 'assets', 'llff_room_cameras.json'), 'w') as f:
         json.dump(cams, f)
+    # LLFF 'fern' cameras (BASELINE config 4), same treatment: cfgs/dataset/llff_fern.yaml has scale 0.33, bound 2
+    with open(os.path.join(REF, 'datasets/nerf_llff_data/fern/transforms_train.json')) as f:
+        fj = json.load(f)
+    fposes = np.array([fr['transform_matrix'] for fr in fj['frames']], dtype=np.float32)
+    fposes[:, :3, 3] *= 0.33
+    fern = {
+        'w': int(fj['w']), 'h': int(fj['h']), 'fl_x': fj['fl_x'], 'fl_y': fj['fl_y'], 'cx': fj['cx'], 'cy': fj['cy'],
+        'scale': 0.33, 'bound': 2.0, 'flip_camera': 3,
+        'poses': [[[float(v) for v in row] for row in p] for p in fposes.astype(np.float64)],
+        'source': 'hkust-vgd/nerfstyle datasets/nerf_llff_data/fern/transforms_train.json (translation x0.33 applied)',
+    }
+    with open(os.path.join(REPO, 'nerfstyle_amd', 'assets', 'llff_fern_cameras.json'), 'w') as f:
+        json.dump(fern, f)
 
     # ---- generate_rays (nerf_lib.py:69-142) --------------------------------------------------
     lib = nerf_lib_mod.nerf_lib
@@ -136,6 +149,53 @@ def main():
     out['loss_nnfm'] = np.array(float(nnfm({'f': fa}, {'f': fb[:, :, :, :10]})))
     gram = loss.GramStyleLoss(['f'])
     out['loss_gram'] = np.array(float(gram({'f': fa}, {'f': fb})))
+
+    # gradients of the NNFM loss w.r.t. the image features (what back-propagates into the renderer)
+    fa_g = fa.clone().requires_grad_(True)
+    nnfm({'f': fa_g}, {'f': fb[:, :, :, :10]}).backward()
+    out['loss_nnfm_grad'] = fa_g.grad.numpy()
+
+    # ---- SemanticStyleLoss (loss.py:116-214), the loss StyleTrainer uses (trainers/style.py:50-52) --------------------
+    out['loss_labels'] = torch.randint(0, 3, (37, 29), generator=g).numpy()
+    out['loss_labels_down'] = loss.labels_downscale(torch.tensor(out['loss_labels']), (12, 10)).numpy()
+    mask = torch.tensor(out['loss_labels']) == 1
+    out['loss_centroid'] = loss.compute_centroid(mask).numpy()
+    # (a) without clusters: plain nearest-neighbour feature matching over all style positions
+    sem = loss.SemanticStyleLoss(['f'], clusters_path=None)
+    sem.init_feats({'f': fb}, num_classes=3)
+    fa_g = fa.clone().requires_grad_(True)
+    v = sem({'f': fa_g}, None, torch.tensor(out['loss_labels']), 0)
+    v.backward()
+    out['loss_sem_plain'] = np.array(float(v))
+    out['loss_sem_plain_grad'] = fa_g.grad.numpy()
+    # (b) with style clusters.  The constructor's clusters branch calls .cuda() (loss.py:138), so the object is built
+    # without a path and given the cluster map by attribute, then the reference's own init_feats / update_matching /
+    # forward run on the CPU unchanged.
+    clusters = torch.randint(0, 3, (40, 44), generator=g)
+    sem2 = loss.SemanticStyleLoss(['f'], clusters_path=None)
+    sem2.use_matching = True
+    sem2.clusters = clusters.clone()
+    sem2.n_clusters = 3
+    sem2.matching = None
+    sem2.init_feats({'f': fb}, num_classes=3)
+    fa_g = fa.clone().requires_grad_(True)
+    v2 = sem2({'f': fa_g}, None, torch.tensor(out['loss_labels']), 0)
+    v2.backward()
+    out['loss_sem_clusters'] = clusters.numpy()
+    out['loss_sem_clusters_small'] = sem2.clusters.numpy()
+    out['loss_sem_matching'] = np.asarray(sem2.matching)
+    out['loss_sem_match'] = np.array(float(v2))
+    out['loss_sem_match_grad'] = fa_g.grad.numpy()
+    out['loss_sem_style_mean'] = sem2.style_feats_mean.numpy()
+    out['loss_sem_style_centroids'] = sem2.style_centroids.numpy()
+    # (c) with a fixed matching given up front (--style_matching, trainers/style.py:47-49)
+    sem3 = loss.SemanticStyleLoss(['f'], clusters_path=None)
+    sem3.use_matching = True
+    sem3.clusters = clusters.clone()
+    sem3.n_clusters = 3
+    sem3.matching = [2, 0, 1]
+    sem3.init_feats({'f': fb}, num_classes=3)
+    out['loss_sem_fixed'] = np.array(float(sem3({'f': fa}, None, torch.tensor(out['loss_labels']), 0)))
 
     np.savez_compressed(os.path.join(HERE, 'reference_python.npz'), **out)
     print('wrote', os.path.join(HERE, 'reference_python.npz'), sorted(out.keys()))

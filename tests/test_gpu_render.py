@@ -447,6 +447,57 @@ def test_deferred_backprop_equals_direct_and_trains_only_colour_table(O, dev):
     assert float(m.arena.grad.abs().max()) == 0.0
 
 
+def test_stylisation_iteration_vgg_semantic_loss_504x378(O, dev):
+    """BASELINE config 3 end to end on one GPU at the shipped LLFF resolution: StyleTrainer.run_iter
+    (trainers/style.py:162-204) = full-frame pass without autograd -> VGG16 'relu3' content MSE + SemanticStyleLoss with
+    style clusters and Hungarian matching (style.py:70-105, loss.py:116-214; the PyTorch losses pinned against the
+    reference in tests/test_losses_cpu.py) -> cached d loss / d pixels -> 6 patch re-renders of 200x200 with autograd ->
+    colour-table-only fused Adam (style.py:25).  The deferred gradient must equal one direct full-frame backward."""
+    from nerfstyle_amd.losses import SemanticStyleLoss
+    from nerfstyle_amd.optim import FusedAdam
+    from nerfstyle_amd.stylize import StyleCriterion, deferred_backprop_step, patch_list
+    from nerfstyle_amd.vgg import VGG16FeatureExtractor
+    r, ref, poses, intr, bits = _setup(dev, cap=256)
+    r.cfg.max_steps = 512                                     # README's stylisation command: --max_steps 512
+    m = r.model
+    W, H = intr.size()
+    assert (W, H) == (504, 378) and len(patch_list(W, H, 200)) == 6
+    g = torch.Generator().manual_seed(5)
+    target = torch.rand(3, H, W, generator=g).to(dev)
+    style = torch.rand(3, 378, 504, generator=g).to(dev)
+    seg = torch.randint(0, 5, (378, 504), generator=g)
+    fx = VGG16FeatureExtractor(['relu3']).to(dev)
+    crit = StyleCriterion(fx, SemanticStyleLoss(['relu3'], clusters=seg), content_lambda=0.001, style_lambda=1.0)
+    crit.init_style(style, num_classes=5)
+    pose = torch.tensor(poses[4], device=dev)
+    opt = FusedAdam(m, lr=0.1, keywords=['x_color_embedder'])
+    SCALE = 65536.0
+
+    def image_loss(rgb, classes):
+        return crit(rgb, target, classes, frame_key=4)[0]
+
+    loss, rgb = deferred_backprop_step(r, pose, image_loss, patch_size=200, loss_scale=SCALE, with_classes=True)
+    assert crit.style_loss.matching is not None and sorted(crit.style_loss.matching) == [0, 1, 2, 3, 4]
+    assert np.isfinite(float(loss)) and rgb.shape == (H, W, 3)
+    g_def = m.arena.grad.clone()
+    m.arena.grad.zero_()
+    out = r.render(pose, None, training=True)
+    (image_loss(out['rgb_map'].view(H, W, 3), out['classes'].detach().view(H, W, 5)) * SCALE).backward()
+    g_dir = m.arena.grad.clone()
+    assert float(g_dir.abs().sum()) > 0
+    assert rel_l2(g_def.cpu().numpy(), g_dir.cpu().numpy()) < 2e-3
+    gt = g_def[:m.table_elems].view(m.rows, 2, 2)
+    assert float(gt[:, 0].abs().max()) == 0.0 and float(gt[:, 1].abs().max()) > 0.0
+    before = m.arena.detach().clone()
+    opt.step(grad_scale=SCALE)
+    after = m.arena.detach()
+    assert torch.equal(before[m.table_elems:], after[m.table_elems:])
+    assert not torch.equal(before[:m.table_elems], after[:m.table_elems])
+    # a second iteration with the updated colour table gives a different, finite loss
+    loss2, _ = deferred_backprop_step(r, pose, image_loss, patch_size=200, loss_scale=SCALE, with_classes=True)
+    assert np.isfinite(float(loss2)) and float(loss2) != float(loss)
+
+
 def test_reconstruction_training_learns_with_occupancy_updates(O, dev):
     """The reference's whole training flow on one camera: Renderer.render(training=True) with
     update_occ ON (update_state every 16 calls on the model's own densities, renderer.py:206-207),
@@ -531,3 +582,76 @@ def test_graph_captured_step_equals_eager_step(O, dev):
         assert abs(float(loss_g) - float(loss_e.detach())) <= 1e-6 * abs(float(loss_e.detach()))
         assert float(grad_g.abs().max()) > 0
         assert rel_l2(grad_g.cpu().numpy(), m.arena.grad.cpu().numpy()) < 1e-4
+
+
+def test_bf16_graph_replayed_training_step(O, dev):
+    """BASELINE config 5's render step on one GPU: bf16 MLP operands + fp32 composite, render + loss + backward replayed as
+    one captured hipGraph, occupancy updates (device-side, no host read) between replays, fused Adam.  A replayed step
+    equals the eager bf16 step, and the bf16 render clears the 40 dB bar against the fp32 oracle pipeline."""
+    from nerfstyle_amd.common import BBox
+    from nerfstyle_amd.config import NetworkConfig, RendererConfig
+    from nerfstyle_amd.graph import GraphedRenderStep
+    from nerfstyle_amd.optim import FusedAdam
+    from nerfstyle_amd.renderer import Renderer
+    from nerfstyle_amd.scene import load_room_cameras
+    from nerfstyle_amd.style_nerf import StyleTCNerf
+    from oracle import torch_port as TP
+    nc = 5
+    ref = TP.Field(num_classes=nc, table_scale=0.5)
+    m = StyleTCNerf(NetworkConfig(), BBox.from_radius(2.0), nc, enc_dtype=torch.float32, use_dir=False, compute_dtype=torch.bfloat16)
+    sd = m.state_dict()
+    sd.update({'x_density_embedder.embeddings': ref.emb_density.detach(), 'x_color_embedder.embeddings': ref.emb_color.detach(),
+               'density_net.params': ref.p_density.detach(), 'color1_net.params': ref.p_color1.detach(),
+               'color2_net.params': ref.p_color2.detach(), 'class_net.params': ref.p_class.detach()})
+    m.load_state_dict(sd)
+    poses, intr, _ = load_room_cameras()
+    r = Renderer(m, RendererConfig.llff(), intr, 2.0, raymarch_channels=3 + nc, samples_per_ray_cap=192).to(dev)
+    grid, bits = small_scene()
+    r.density_grid = torch.tensor(grid, device=dev)
+    r.density_bitfield = torch.tensor(bits, device=dev)
+    r.update_occ = False
+    # ---- PSNR of the bf16 render vs the fp32 oracle pipeline -------------------------------------
+    np.random.seed(1)
+    pix = np.random.choice(intr.w * intr.h, 4096, replace=False)
+    ro, rd = O.generate_rays(poses[0], intr.w, intr.h, intr.fx, intr.fy, intr.cx, intr.cy, 3, pix_indices=pix)
+    rgb_o, _, _, cnt = _oracle_render(O, ref, bits, ro, rd)
+    with torch.no_grad():
+        out = r.render(torch.tensor(poses[0], device=dev), None, training=True, pix_subset=torch.tensor(pix, device=dev))
+    psnr = O.compute_psnr(float(np.mean((out['rgb_map'].cpu().numpy() - rgb_o) ** 2)))
+    assert cnt > 4096 * 8 and psnr > 40.0, psnr
+    # ---- graph replay == eager, bf16 ----------------------------------------------------------------
+    n = 4096
+    g = torch.Generator(device=dev)
+    g.manual_seed(3)
+    target = torch.rand(intr.w * intr.h, 3, device=dev, generator=g)
+
+    def loss_fn(o, p):
+        return torch.mean((o['rgb_map'] - target[p]) ** 2) + 1e-3 * o['classes'].square().mean()
+
+    step = GraphedRenderStep(r, n, loss_fn)
+    pose_t = torch.tensor(poses, device=dev)
+    step.capture(pose_t[0], torch.randperm(intr.w * intr.h, device=dev, generator=g)[:n])
+    for k in (2, 7):
+        p = torch.randperm(intr.w * intr.h, device=dev, generator=g)[:n]
+        m.arena.grad.zero_()
+        loss_g = step(pose_t[k], p).clone()
+        grad_g = m.arena.grad.clone()
+        m.arena.grad.zero_()
+        o = r.render(pose_t[k], None, training=True, pix_subset=p)
+        loss_e = loss_fn(o, p)
+        loss_e.backward()
+        assert abs(float(loss_g) - float(loss_e.detach())) <= 1e-6 * abs(float(loss_e.detach()))
+        assert float(grad_g.abs().max()) > 0 and rel_l2(grad_g.cpu().numpy(), m.arena.grad.cpu().numpy()) < 1e-4
+    # ---- with occupancy updates on: they run between replays on the device, the graph keeps replaying ---------------
+    r.update_occ = True
+    r.local_step = 0
+    step2 = GraphedRenderStep(r, n, loss_fn)
+    opt = FusedAdam(m, lr=1e-3)
+    m.arena.grad.zero_()
+    losses = []
+    for it in range(18):                      # updates at steps 0 and 16
+        p = torch.randperm(intr.w * intr.h, device=dev, generator=g)[:n]
+        losses.append(float(step2(pose_t[it % 8], p)))
+        opt.step()
+    assert r.local_step == 18 and int(r._occ_state[0]) == 2 and np.all(np.isfinite(losses))
+    assert int(r.density_bitfield.count_nonzero()) > 0

@@ -6,7 +6,7 @@ On the GPU box (Measurement):
   (same for WRITE_SIZE and TCC_EA0_ATOMIC_sum: one counter group per pass, kernel trace only)
 then here:  python tools/make_profiles.py gpurun_out r01
 """
-import collections, csv, glob, json, os, shutil, sys
+import collections, csv, glob, json, os, shutil, subprocess, sys
 
 
 def find(d, name):
@@ -40,6 +40,7 @@ def main(root, tag, samples_per_launch):
         'source': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / --pmc TCC_EA0_ATOMIC_sum (three separate passes, '
                   '--kernel-trace only), python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline (default workload)',
         'samples_per_launch': samples_per_launch,
+        'commit': subprocess.run(['git', 'rev-parse', '--short', 'HEAD'], capture_output=True, text=True).stdout.strip() or None,
         'correction': 'MI355X_MICROARCH.md HBM section: bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (FETCH_SIZE half-counts '
                       'wide reads; WRITE_SIZE exact, float atomics are counted as writes); gather access widths are uncalibrated',
         'kernels': {},
