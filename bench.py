@@ -106,12 +106,12 @@ def cpu_baseline(budget_s, nc):
     calib = {}
     for nt in cand:
         torch.set_num_threads(nt)
-        one(0, 100)
-        calib[nt] = one(100, 200)[1] / 200.0                 # seconds per ray, forward + backward
+        one(0, 50)
+        calib[nt] = one(50, 100)[1] / 100.0                  # seconds per ray, forward + backward
     nt = min(calib, key=calib.get)
     torch.set_num_threads(nt)
     left = budget_s - (time.perf_counter() - t_start)
-    rep_rays = int(max(100, min(40000, left / 6.5 / calib[nt])))
+    rep_rays = int(max(50, min(40000, left / 6.5 / calib[nt])))
     reps, fwd = [], []
     one(0, rep_rays)                                          # warm-up at the repetition size
     for i in range(5):
