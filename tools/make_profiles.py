@@ -50,6 +50,8 @@ def main(root, tag, samples_per_launch):
                                   'k_march_count', 'k_march_emit', 'k_adam') if n in k), None)
         if not short:
             continue
+        if short == 'k_field_fwd' and ('Lb1EEv9FieldArgs' in k or 'true>' in k):
+            short = 'k_field_fwd_sigma_only'          # the occupancy update's sigma-only instantiation (4.19 M points)
         fb, wb = fetch.get(k, 0.0), write.get(k, 0.0)
         e = {'FETCH_SIZE_KB': round(fb, 1), 'WRITE_SIZE_KB': round(wb, 1),
              'traffic_bytes_per_launch': int((2 * fb + wb) * 1024),
