@@ -372,7 +372,7 @@ __device__ __forceinline__ void field_scatter_seq(SeqState &st, const NsrLevel *
 // 29.7 / 19.3 of the ray-order run tracker, at a third of its instructions).
 constexpr int LAT_MAX_SLOTS = 1024;                  // float4 slots per wave (16 KB)
 constexpr int LAT_KEY_BITS = 10;                     // must match nsr_sample_order's quantisation
-constexpr size_t BWD_LAT_BYTES_PER_WAVE = (size_t)LAT_MAX_SLOTS * 16 + 16 * 16 * 16;           // lattice + staging
+constexpr size_t BWD_LAT_BYTES_PER_WAVE = (size_t)LAT_MAX_SLOTS * 16 + 256 + 16 * 16 * 16;     // lattice + row scratch + staging
 constexpr size_t BWD_LDS_BYTES_SORTED = (size_t)FW_TOTAL * 2 + (size_t)BW_TOTAL * 2 + 16 * sizeof(NsrLevel) +
                                         (BWD_THREADS / 64) * BWD_LAT_BYTES_PER_WAVE;
 constexpr uint32_t LAT_NONE = 0xFFFFFFFFu;
@@ -397,41 +397,50 @@ static bool lat_geometry(const NsrLevel *lv, LatGeom &g) {
 }
 
 // Flushes level l's lattice, anchored at cell (b0, b1, b2) -- wave-uniform arguments -- and clears it.
+// 64 slots per trip, three phases so that nothing is computed four times and every LDS round trip is shared:
+//   1. one lane per slot: read its float4, test it, and (touched slots only) compute the table row ONCE -> rows[lane];
+//   2. four groups of 16 slots, skipped when empty: lane (t = lane >> 2, i = lane & 3) reads component i of slot
+//      16q + t and its row and issues the atomic -- the four dwords of a row leave as ONE 16-byte request, x-neighbouring
+//      corners (consecutive slots) share their 64-byte line;
+//   3. the touched slots are cleared.
 template <int S>
-__device__ __forceinline__ void lat_flush_level(float *__restrict__ lf, uint32_t b0, uint32_t b1, uint32_t b2, const NsrLevel &lv,
-                                                float *__restrict__ gt, int lane, bool td, bool tc) {
+__device__ __forceinline__ void lat_flush_level(float4 *__restrict__ lat4, uint32_t *__restrict__ rows, uint32_t b0, uint32_t b1, uint32_t b2,
+                                                const NsrLevel &lv, float *__restrict__ gt, int lane, bool td, bool tc) {
     constexpr int NC = S * S * S;
     const int t = lane >> 2, i = lane & 3;
     const bool on = (i < 2) ? td : tc;
-    // two groups of 16 corners per trip: both LDS reads are in flight before either is used (one wave per SIMD:
-    // a dependent LDS round trip per group would be fully exposed)
-#pragma unroll 1
-    for (int k0 = 0; k0 < NC; k0 += 32) {
-        const int ka = k0 + t, kb = k0 + 16 + t;
-        const float va = ka < NC ? lf[ka * 4 + i] : 0.0f;
-        const float vb = kb < NC ? lf[kb * 4 + i] : 0.0f;
-        const unsigned long long ma = __ballot(va != 0.0f), mb = __ballot(vb != 0.0f);
-        const bool ra = (ma >> (lane & ~3)) & 0xFull, rb = (mb >> (lane & ~3)) & 0xFull;   // any component of the corner non-zero
-        if (ra) {
-            const int z = ka / (S * S), r = ka - z * (S * S), y = r / S, x = r - y * S;
-            const uint32_t row = lv.offset + nsr_grid_row(lv, b0 + (uint32_t)x, b1 + (uint32_t)y, b2 + (uint32_t)z, 0u);
-#ifndef NSR_ABL_NO_ATOMIC
-            if (on) atomicAdd(gt + (size_t)row * 4 + i, va);
-#else
-            if (on && row == 0xFFFFFFFFu) gt[i] = va;
-#endif
-            lf[ka * 4 + i] = 0.0f;
+    const float *lf = reinterpret_cast<const float *>(lat4);
+#pragma unroll
+    for (int k0 = 0; k0 < NC; k0 += 64) {
+        NSR_STAT(2, 1);
+        const int k = k0 + lane;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (k < NC) v = lat4[k];
+        const bool nz = seq_nonzero(v);
+        const unsigned long long m = __ballot(nz);
+        if (m == 0ull) continue;                                          // wave-uniform: nothing touched in these slots
+        if (nz) {
+            const int z = k / (S * S), r = k - z * (S * S), y = r / S, x = r - y * S;
+            rows[lane] = lv.offset + nsr_grid_row(lv, b0 + (uint32_t)x, b1 + (uint32_t)y, b2 + (uint32_t)z, 0u);
         }
-        if (rb) {
-            const int z = kb / (S * S), r = kb - z * (S * S), y = r / S, x = r - y * S;
-            const uint32_t row = lv.offset + nsr_grid_row(lv, b0 + (uint32_t)x, b1 + (uint32_t)y, b2 + (uint32_t)z, 0u);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            if (k0 + 16 * q >= NC) break;
+            if (((m >> (16 * q)) & 0xFFFFull) == 0ull) continue;          // wave-uniform
+            const bool rec = (m >> (16 * q + t)) & 1ull;
+            if (rec) {
+                const float val = lf[(k0 + 16 * q + t) * 4 + i];
+                const uint32_t row = rows[16 * q + t];
 #ifndef NSR_ABL_NO_ATOMIC
-            if (on) atomicAdd(gt + (size_t)row * 4 + i, vb);
+                if (on) atomicAdd(gt + (size_t)row * 4 + i, val);
 #else
-            if (on && row == 0xFFFFFFFFu) gt[i] = vb;
+                if (on && row == 0xFFFFFFFFu) gt[i] = val;
 #endif
-            lf[kb * 4 + i] = 0.0f;
+            }
         }
+        __builtin_amdgcn_wave_barrier();
+        if (nz) lat4[k] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
 }
 
@@ -444,12 +453,14 @@ __device__ __forceinline__ void lat_flush_dispatch(float4 *__restrict__ lat, int
     const uint32_t o1 = (uint32_t)__builtin_amdgcn_readlane((int)st.b1, fl * 4);
     const uint32_t o2 = (uint32_t)__builtin_amdgcn_readlane((int)st.b2, fl * 4);
     const NsrLevel flv = lds_lv[fl];
-    float *lf = reinterpret_cast<float *>(lat + (flv.pad_ >> 8));
+    NSR_STAT(1, 1);
+    float4 *lf = lat + (flv.pad_ >> 8);
+    uint32_t *rows = reinterpret_cast<uint32_t *>(lat + LAT_MAX_SLOTS);       // 64-entry row scratch behind the lattices
     switch (flv.pad_ & 0xFFu) {
-    case 3: lat_flush_level<3>(lf, o0, o1, o2, flv, gt, lane, td, tc); break;
-    case 4: lat_flush_level<4>(lf, o0, o1, o2, flv, gt, lane, td, tc); break;
-    case 5: lat_flush_level<5>(lf, o0, o1, o2, flv, gt, lane, td, tc); break;
-    default: lat_flush_level<6>(lf, o0, o1, o2, flv, gt, lane, td, tc); break;
+    case 3: lat_flush_level<3>(lf, rows, o0, o1, o2, flv, gt, lane, td, tc); break;
+    case 4: lat_flush_level<4>(lf, rows, o0, o1, o2, flv, gt, lane, td, tc); break;
+    case 5: lat_flush_level<5>(lf, rows, o0, o1, o2, flv, gt, lane, td, tc); break;
+    default: lat_flush_level<6>(lf, rows, o0, o1, o2, flv, gt, lane, td, tc); break;
     }
 }
 
@@ -486,6 +497,7 @@ __device__ __forceinline__ void field_scatter_lattice(LatState &st, uint32_t &cu
         if (key != cur_key) {
             // ---- the walk enters another block: re-anchor every level at the cell of the block's origin ----
             cur_key = key;
+            NSR_STAT(0, 1);
             const float rk = 1.0f / kq;
             const float o0 = (float)(key & ((1u << LAT_KEY_BITS) - 1u)) * rk, o1 = (float)((key >> LAT_KEY_BITS) & ((1u << LAT_KEY_BITS) - 1u)) * rk,
                         o2 = (float)(key >> (2 * LAT_KEY_BITS)) * rk;
@@ -594,7 +606,7 @@ k_field_bwd(FieldBwdArgs b) {
     if (SORTED) {
         char *base = wave_lds + (size_t)wave * BWD_LAT_BYTES_PER_WAVE;
         lat = reinterpret_cast<float4 *>(base);
-        qbase_g = base + (size_t)LAT_MAX_SLOTS * 16;
+        qbase_g = base + (size_t)LAT_MAX_SLOTS * 16 + 256;
         for (int k = lane; k < LAT_MAX_SLOTS; k += 64) lat[k] = make_float4(0.f, 0.f, 0.f, 0.f);
     } else {
         char *qbase = wave_lds + (size_t)wave * BWD_QUEUE_BYTES_PER_WAVE;
@@ -702,15 +714,6 @@ k_field_bwd(FieldBwdArgs b) {
         NSR_TACC(0, tk0, tk1);
         const uint32_t m = tile * 16 + s;
         const bool valid = m < Mc;
-        // SORTED: the next tile's loads go out HERE, a whole iteration before they are consumed.  The lattice flushes issue
-        // their atomics inline, and one in-order vmcnt covers loads and atomics: a load can only be waited for together
-        // with everything issued before the wait -- so the wait at the loop top (for `cur`, issued an iteration ago) costs
-        // at most the trip of the last flush's atomics, and these loads have the MLP section and the scatter to land.
-        TileIn nxt_sorted = cur;
-        if (SORTED && tile + 1 < w_end) {
-            nxt_sorted = load_tile(tile + 1, idx_next);
-            if (tile + 2 < w_end) idx_next = fetch_idx(tile + 2);
-        }
         const float u0 = valid ? field_unit(cur.x0, a.bmin[0], a.bsize[0]) : 0.f;
         const float u1 = valid ? field_unit(cur.x1, a.bmin[1], a.bsize[1]) : 0.f;
         const float u2 = valid ? field_unit(cur.x2, a.bmin[2], a.bsize[2]) : 0.f;
@@ -862,9 +865,15 @@ k_field_bwd(FieldBwdArgs b) {
         // Next tile's loads go out BEFORE this tile's scatter: the scatter touches LDS only (its records are
         // turned into atomics by the pace points of the next tile), so by the next loop top both these loads
         // and the atomics issued ahead of them (vmcnt retires in order) have had the whole scatter to land.
+        // Both walks: the loads sit between the MLP section (whose registers are dead here) and the scatter.  SORTED: the
+        // permutation entry was fetched one tile ahead, so nothing here depends on a load of the same batch.  (Issuing
+        // these at the loop top instead -- a whole iteration of slack -- keeps 16 more registers live through the MLP
+        // section and spills: measured slower.)
         TileIn nxt = cur;
-        if (!SORTED && tile + 1 < w_end) nxt = load_tile(tile + 1, fetch_idx(tile + 1));
-        if (SORTED) nxt = nxt_sorted;
+        if (tile + 1 < w_end) {
+            nxt = load_tile(tile + 1, SORTED ? idx_next : fetch_idx(tile + 1));
+            if (SORTED && tile + 2 < w_end) idx_next = fetch_idx(tile + 2);
+        }
         NSR_TICK(tk3);
         NSR_TACC(3, tk2, tk3);
         if (td || tc) {

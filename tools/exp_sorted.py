@@ -64,7 +64,7 @@ def main():
         for it in range(4):
             e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
             e[0].record()
-            pp = m.sample_order(xyzs, m_dev=counter, sort_prefix=total + 65536) if p else None
+            pp = m.sample_order(xyzs, m_dev=counter, sort_prefix=(0 if os.environ.get('EXP_IDENTITY_PERM') else total + 65536)) if p else None
             e[1].record()
             sig, rgb = m.field(xyzs, False, counter, perm=pp)
             e[2].record()
