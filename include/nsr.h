@@ -241,14 +241,19 @@ int nsr_field_backward(const nsr_field_desc *desc, const void *tables, const flo
                        const float *xyzs, uint32_t M, const int32_t *m_dev, const float *grad_sigmas,
                        const float *grad_rgbs, float *grad_tables, float *grad_mlp,
                        int train_density_table, int train_color_table, const void *feats,
-                       const uint32_t *perm, nsr_stream_t stream);
+                       const uint32_t *perm, void *workspace, nsr_stream_t stream);
+/* perm != NULL (nsr_sample_order): the MLP backward writes every sample's encoder-output gradient (256 B) to
+ * `workspace` and a second, high-occupancy kernel accumulates the table gradient walking the samples in perm's
+ * spatial order (LDS lattices, one merged atomic record per touched corner; csrc/table_scatter.hip).  Pays on dense
+ * (full-frame) batches; results equal the perm == NULL call up to fp32 summation order.
+ * workspace: nsr_field_backward_workspace_bytes(M, with_perm) bytes, 16-byte aligned (0 / NULL without perm). */
+uint64_t nsr_field_backward_workspace_bytes(uint32_t M, int with_perm);
 
 /* Spatial processing order of marched samples (no reference counterpart; see csrc/sample_order.hip): perm [M] u32 =
  * indices of the first min(m_dev[0], M) samples in Morton order of their encoder input (10 bits per axis, stable: ray
  * order inside a 4^3-finest-cell block), followed by the remaining slots.  sort_prefix <= M: how many leading slots
  * take part in the sort (the emitted count lives on the device; pass an estimate >= it, or M; a smaller value is still
- * correct -- the slots past it keep identity order).  With perm the fused backward accumulates table gradients in
- * LDS lattice tiles and issues ~3x fewer atomic requests on dense (full-frame) batches.
+ * correct -- the slots past it keep identity order).  Consumed by nsr_field_backward (table scatter in spatial order).
  * workspace: nsr_sample_order_workspace_bytes(M) bytes, 256-byte aligned.  bbox_min / bbox_size: HOST float[3]. */
 uint64_t nsr_sample_order_workspace_bytes(uint32_t M);
 int nsr_sample_order(const float *xyzs, uint32_t M, const int32_t *m_dev, uint32_t sort_prefix,

@@ -64,7 +64,8 @@ SIGNATURES = {
     'nsr_mlp_forward': (i32, [vp, vp, u32, u32, u32, u32, u32, i32, i32, vp, vp]),
     'nsr_mlp_backward': (i32, [vp, vp, vp, vp, u32, u32, u32, u32, u32, i32, i32, vp, vp, vp]),
     'nsr_field_forward': (i32, [ctypes.POINTER(FieldDesc), vp, vp, vp, u32, vp, vp, vp, vp, vp, vp]),
-    'nsr_field_backward': (i32, [ctypes.POINTER(FieldDesc), vp, vp, vp, u32, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp]),
+    'nsr_field_backward': (i32, [ctypes.POINTER(FieldDesc), vp, vp, vp, u32, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp]),
+    'nsr_field_backward_workspace_bytes': (u64, [u32, i32]),
     'nsr_sample_order_workspace_bytes': (u64, [u32]),
     'nsr_sample_order': (i32, [vp, u32, vp, u32, ctypes.POINTER(f32), ctypes.POINTER(f32), vp, vp, vp]),
     'nsr_cast_f32_to_f16': (i32, [vp, vp, u64, vp]),

@@ -13,8 +13,8 @@ CSRC = os.path.join(HERE, 'csrc')
 OBJ = os.path.join(HERE, 'csrc', '_obj')
 LIB = os.path.join(HERE, 'libnsr_hip.so')
 ARCH = 'gfx950'
-SOURCES = ['raymarch.hip', 'occupancy.hip', 'sample_order.hip', 'gridenc.hip', 'field.hip', 'field_bwd.hip', 'mlp.hip', 'optim.hip']
-HEADERS = ['nsr_common.h', 'rm_util.h', 'mfma_tiles.h', 'field_common.h', os.path.join('..', '..', 'include', 'nsr.h')]
+SOURCES = ['raymarch.hip', 'occupancy.hip', 'sample_order.hip', 'gridenc.hip', 'field.hip', 'field_bwd.hip', 'table_scatter.hip', 'mlp.hip', 'optim.hip']
+HEADERS = ['nsr_common.h', 'rm_util.h', 'table_scatter.h', 'mfma_tiles.h', 'field_common.h', os.path.join('..', '..', 'include', 'nsr.h')]
 FLAGS = ['-O3', '-fPIC', '-std=c++17', '--offload-arch=' + ARCH, '-Wall', '-Wno-unused-function']
 
 

@@ -18,6 +18,7 @@
 // directions, so dX arrives from the MFMA on the lane that scatters it.
 #include <stdio.h>
 #include "field_common.h"
+#include "table_scatter.h"
 
 // ---- backward LDS image (units: shorts) ------------------------------------------------------
 constexpr int BW_R3T = 0;        // r3^T  [64 x 16]  4 frag16
@@ -37,10 +38,6 @@ constexpr size_t BWD_QUEUE_BYTES_PER_WAVE = 1024 * 16 + 1024 * 4 + 16 * 16 * 16;
 constexpr size_t BWD_LDS_BYTES = (size_t)FW_TOTAL * 2 + (size_t)BW_TOTAL * 2 + 16 * sizeof(NsrLevel) +
                                  (BWD_THREADS / 64) * BWD_QUEUE_BYTES_PER_WAVE;
 
-struct LatGeom {
-    uint16_t base[16];      // first slot of the level's lattice
-    uint8_t S[16];          // corners per axis
-};
 
 struct FieldBwdArgs {
     FieldArgs f;
@@ -50,7 +47,7 @@ struct FieldBwdArgs {
     float *grad_mlp;
     int train_density, train_color;
     uint32_t nc;
-    LatGeom lat;               // SORTED kernels: lattice geometry (lat_geometry)
+    float4 *gout;              // GOUT kernels: [M][16 levels] float4 = d loss / d (density f0, f1, colour f0, f1) of every sample
 };
 
 template <int CD>
@@ -354,222 +351,13 @@ __device__ __forceinline__ void field_scatter_seq(SeqState &st, const NsrLevel *
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------
-// Lattice accumulator (SORTED kernels: samples walked in the spatial order of nsr_sample_order).
-//
-// The order's key is the sample's BLOCK: its encoder input quantised to 10 bits per axis (a 4^3 group of finest-level
-// cells for the reference's 16-level grid).  Consecutive samples -- of MANY rays -- share a block, and a block touches
-// only a handful of cells on every level: at most ceil(res_l / 1024) + 1 per axis.  So the wave keeps, per level, a
-// small LATTICE of corner gradients in LDS anchored at the cell of the block's origin (5^3 corners on the two finest
-// levels, 4^3 on the next two, 3^3 below: 702 float4 = 11 KB per wave).  Lane = (level l = lane >> 2, y/z corner pair
-// p = lane & 3) walks the tile's 16 samples in order and adds its two x corners' contributions with a plain LDS
-// read-modify-write: within a step the 64 lanes touch 128 different slots and steps are sequential, so no atomics
-// are needed; the lattice is addressed by cell coordinates, so nothing is hashed per sample.  When the walk enters
-// a new block every level re-anchors; a level whose anchor cell did not change (the coarse ones: a block is a
-// fraction of their cell) keeps accumulating, the others are flushed cooperatively -- 16 corners per wave-instruction,
-// 4 lanes per corner, so the four dwords of a row leave as ONE 16-byte request, one merged record per corner a block
-// touched (tools/sorted_scatter_sim.py: ~6 records and ~3 atomic requests per sample on the bench scene against
-// 29.7 / 19.3 of the ray-order run tracker, at a third of its instructions).
-constexpr int LAT_MAX_SLOTS = 1024;                  // float4 slots per wave (16 KB)
-constexpr int LAT_KEY_BITS = 10;                     // must match nsr_sample_order's quantisation
-constexpr size_t BWD_LAT_BYTES_PER_WAVE = (size_t)LAT_MAX_SLOTS * 16 + 256 + 16 * 16 * 16;     // lattice + row scratch + staging
-constexpr size_t BWD_LDS_BYTES_SORTED = (size_t)FW_TOTAL * 2 + (size_t)BW_TOTAL * 2 + 16 * sizeof(NsrLevel) +
-                                        (BWD_THREADS / 64) * BWD_LAT_BYTES_PER_WAVE;
-constexpr uint32_t LAT_NONE = 0xFFFFFFFFu;
-struct LatState {
-    uint32_t b0, b1, b2;     // anchor cell of this lane's level (LAT_NONE: nothing accumulated yet)
-};
-
-// Host: lattice geometry for the 1/1024 blocks of the sample order.  A block spans e = res / 1024 cells of a level:
-// it touches at most floor(e) + 2 cells per axis (exactly e when the level's cells tile the block), one more corner.
-static bool lat_geometry(const NsrLevel *lv, LatGeom &g) {
-    uint32_t total = 0;
-    for (int l = 0; l < 16; l++) {
-        const uint32_t res = lv[l].resolution, blocks = 1u << LAT_KEY_BITS;
-        const uint32_t cells = (res % blocks == 0) ? res / blocks : res / blocks + 2;
-        const uint32_t S = cells + 1;
-        if (S > 6) return false;
-        g.S[l] = (uint8_t)S;
-        g.base[l] = (uint16_t)total;
-        total += S * S * S;
-    }
-    return total <= (uint32_t)LAT_MAX_SLOTS;
-}
-
-// Flushes level l's lattice, anchored at cell (b0, b1, b2) -- wave-uniform arguments -- and clears it.
-// 64 slots per trip, three phases so that nothing is computed four times and every LDS round trip is shared:
-//   1. one lane per slot: read its float4, test it, and (touched slots only) compute the table row ONCE -> rows[lane];
-//   2. four groups of 16 slots, skipped when empty: lane (t = lane >> 2, i = lane & 3) reads component i of slot
-//      16q + t and its row and issues the atomic -- the four dwords of a row leave as ONE 16-byte request, x-neighbouring
-//      corners (consecutive slots) share their 64-byte line;
-//   3. the touched slots are cleared.
-template <int S>
-__device__ __forceinline__ void lat_flush_level(float4 *__restrict__ lat4, uint32_t *__restrict__ rows, uint32_t b0, uint32_t b1, uint32_t b2,
-                                                const NsrLevel &lv, float *__restrict__ gt, int lane, bool td, bool tc) {
-    constexpr int NC = S * S * S;
-    const int t = lane >> 2, i = lane & 3;
-    const bool on = (i < 2) ? td : tc;
-    const float *lf = reinterpret_cast<const float *>(lat4);
-#pragma unroll
-    for (int k0 = 0; k0 < NC; k0 += 64) {
-        NSR_STAT(2, 1);
-        const int k = k0 + lane;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (k < NC) v = lat4[k];
-        const bool nz = seq_nonzero(v);
-        const unsigned long long m = __ballot(nz);
-        if (m == 0ull) continue;                                          // wave-uniform: nothing touched in these slots
-        if (nz) {
-            const int z = k / (S * S), r = k - z * (S * S), y = r / S, x = r - y * S;
-            rows[lane] = lv.offset + nsr_grid_row(lv, b0 + (uint32_t)x, b1 + (uint32_t)y, b2 + (uint32_t)z, 0u);
-        }
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            if (k0 + 16 * q >= NC) break;
-            if (((m >> (16 * q)) & 0xFFFFull) == 0ull) continue;          // wave-uniform
-            const bool rec = (m >> (16 * q + t)) & 1ull;
-            if (rec) {
-                const float val = lf[(k0 + 16 * q + t) * 4 + i];
-                const uint32_t row = rows[16 * q + t];
-#ifndef NSR_ABL_NO_ATOMIC
-                if (on) atomicAdd(gt + (size_t)row * 4 + i, val);
-#else
-                if (on && row == 0xFFFFFFFFu) gt[i] = val;
-#endif
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-        if (nz) lat4[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-}
-
-// The geometry of level fl comes from the LDS copy of the level table (pad_ = S | base << 8): a read from the
-// kernel-argument segment here would be a vector-memory load, and waiting for it means waiting for every atomic in flight.
-__device__ __forceinline__ void lat_flush_dispatch(float4 *__restrict__ lat, int fl, const LatState &st,
-                                                   const NsrLevel *__restrict__ lds_lv, float *__restrict__ gt, int lane, bool td, bool tc) {
-    const uint32_t o0 = (uint32_t)__builtin_amdgcn_readlane((int)st.b0, fl * 4);
-    if (o0 == LAT_NONE) return;
-    const uint32_t o1 = (uint32_t)__builtin_amdgcn_readlane((int)st.b1, fl * 4);
-    const uint32_t o2 = (uint32_t)__builtin_amdgcn_readlane((int)st.b2, fl * 4);
-    const NsrLevel flv = lds_lv[fl];
-    NSR_STAT(1, 1);
-    float4 *lf = lat + (flv.pad_ >> 8);
-    uint32_t *rows = reinterpret_cast<uint32_t *>(lat + LAT_MAX_SLOTS);       // 64-entry row scratch behind the lattices
-    switch (flv.pad_ & 0xFFu) {
-    case 3: lat_flush_level<3>(lf, rows, o0, o1, o2, flv, gt, lane, td, tc); break;
-    case 4: lat_flush_level<4>(lf, rows, o0, o1, o2, flv, gt, lane, td, tc); break;
-    case 5: lat_flush_level<5>(lf, rows, o0, o1, o2, flv, gt, lane, td, tc); break;
-    default: lat_flush_level<6>(lf, rows, o0, o1, o2, flv, gt, lane, td, tc); break;
-    }
-}
-
-// One tile of 16 (spatially ordered) samples.  G: this wave's [16 levels][16 samples] float4 staging buffer; (u0,u1,u2):
-// this lane's SAMPLE (lane & 15) position; sg[i]: its gradients for level lvl[i]; live: this lane's sample is inside.
-__device__ __forceinline__ void field_scatter_lattice(LatState &st, uint32_t &cur_key,
-                                                      const NsrLevel *__restrict__ lds_lv, float4 *__restrict__ G,
-                                                      float4 *__restrict__ lat, float *__restrict__ gt, float u0, float u1, float u2,
-                                                      bool live, const float4 (&sg)[4], int lane, bool td, bool tc,
-                                                      uint32_t myS, uint32_t mybase) {
-#ifdef NSR_ABL_NO_SCATTER
-    if (lane >= 0) return;
-#endif
-    const int s = lane & 15, g = lane >> 4;
-    const int lvl[4] = {2 * g, 2 * g + 1, 8 + 2 * g, 9 + 2 * g};
-#pragma unroll
-    for (int i = 0; i < 4; i++) G[lvl[i] * 16 + s] = sg[i];
-    const uint32_t live16 = (uint32_t)(__ballot(live) & 0xFFFFull);      // lanes 0..15 are samples 0..15
-    // this lane's sample's block: the sort key's quantisation (sample_order.hip), 10 bits per axis
-    const float kq = (float)(1 << LAT_KEY_BITS);
-    const uint32_t q0 = (uint32_t)fminf(fmaxf(u0 * kq, 0.0f), kq - 1.0f), q1 = (uint32_t)fminf(fmaxf(u1 * kq, 0.0f), kq - 1.0f),
-                   q2 = (uint32_t)fminf(fmaxf(u2 * kq, 0.0f), kq - 1.0f);
-    const uint32_t bkey = q0 | (q1 << LAT_KEY_BITS) | (q2 << (2 * LAT_KEY_BITS));
-    __builtin_amdgcn_wave_barrier();
-    const int l = lane >> 2, py = lane & 1, pz = (lane >> 1) & 1;
-    const NsrLevel lv = lds_lv[l];
-    const uint32_t S = myS;
-    float4 *const mylat = lat + mybase + ((uint32_t)pz * S + (uint32_t)py) * S;
-#pragma unroll 2
-    for (int step = 0; step < 16; step++) {
-        if (!((live16 >> step) & 1u)) continue;                            // wave-uniform
-        const float4 gr = G[l * 16 + step];
-        const uint32_t key = (uint32_t)__builtin_amdgcn_readlane((int)bkey, step);
-        if (key != cur_key) {
-            // ---- the walk enters another block: re-anchor every level at the cell of the block's origin ----
-            cur_key = key;
-            NSR_STAT(0, 1);
-            const float rk = 1.0f / kq;
-            const float o0 = (float)(key & ((1u << LAT_KEY_BITS) - 1u)) * rk, o1 = (float)((key >> LAT_KEY_BITS) & ((1u << LAT_KEY_BITS) - 1u)) * rk,
-                        o2 = (float)(key >> (2 * LAT_KEY_BITS)) * rk;
-            float ff;
-            uint32_t n0, n1, n2;
-            nsr_grid_locate(o0, lv.resolution, 1, ff, n0);
-            nsr_grid_locate(o1, lv.resolution, 1, ff, n1);
-            nsr_grid_locate(o2, lv.resolution, 1, ff, n2);
-            const bool chg = (n0 != st.b0) | (n1 != st.b1) | (n2 != st.b2);
-            unsigned long long mm = __ballot(chg);
-            while (mm) {
-                const int fl = (int)(__builtin_ctzll(mm) >> 2);
-                mm &= ~(0xFull << (fl * 4));
-                lat_flush_dispatch(lat, fl, st, lds_lv, gt, lane, td, tc);
-            }
-            if (chg) { st.b0 = n0; st.b1 = n1; st.b2 = n2; }
-        }
-        const float su0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, u0), step));
-        const float su1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, u1), step));
-        const float su2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, u2), step));
-        float f0, f1, f2;
-        uint32_t c0, c1, c2;
-        nsr_grid_locate(su0, lv.resolution, 1, f0, c0);
-        nsr_grid_locate(su1, lv.resolution, 1, f1, c1);
-        nsr_grid_locate(su2, lv.resolution, 1, f2, c2);
-        // cell relative to the anchor: 0 .. S - 2 by construction (the sample lies in the block the anchor was taken from;
-        // floor(u * res) is monotonic in u).  The clamp only keeps a violated assumption inside the wave's own LDS.
-        const uint32_t d0 = c0 - st.b0, d1 = c1 - st.b1, d2 = c2 - st.b2;
-        const uint32_t r0 = min(d0, S - 2u), r1 = min(d1, S - 2u), r2 = min(d2, S - 2u);
-        // this sample's contribution to the lane's two x corners: (wx*wy)*wz, the product order of the forward
-        const float wy = py ? f1 : 1 - f1, wz = pz ? f2 : 1 - f2;
-        float wA = ((1 - f0) * wy) * wz, wB = (f0 * wy) * wz;
-        if ((d0 | d1 | d2) > S - 2u && max(d0, max(d1, d2)) > S - 2u) {
-            // fp32 rounding put the cell one past the lattice (u * res of a sample at the very end of its block can round
-            // up across a cell boundary that the block's real extent stops short of): this sample's two corners go
-            // straight to the table, exactly; the (clamped) lattice slots get nothing
-            const uint32_t rowA = lv.offset + nsr_grid_row(lv, c0, c1 + (uint32_t)py, c2 + (uint32_t)pz, 0u);
-            const uint32_t rowB = lv.offset + nsr_grid_row(lv, c0 + 1u, c1 + (uint32_t)py, c2 + (uint32_t)pz, 0u);
-            const float ga[4] = {gr.x, gr.y, gr.z, gr.w};
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                if ((i < 2 ? td : tc) && ga[i] != 0.0f) {
-                    atomicAdd(gt + (size_t)rowA * 4 + i, wA * ga[i]);
-                    atomicAdd(gt + (size_t)rowB * 4 + i, wB * ga[i]);
-                }
-            }
-            wA = 0.0f;
-            wB = 0.0f;
-        }
-        float4 *const slot = mylat + ((r2 * S + r1) * S + r0);
-        float4 a = slot[0], b = slot[1];
-        a.x = fmaf(wA, gr.x, a.x); a.y = fmaf(wA, gr.y, a.y); a.z = fmaf(wA, gr.z, a.z); a.w = fmaf(wA, gr.w, a.w);
-        b.x = fmaf(wB, gr.x, b.x); b.y = fmaf(wB, gr.y, b.y); b.z = fmaf(wB, gr.z, b.z); b.w = fmaf(wB, gr.w, b.w);
-        slot[0] = a;
-        slot[1] = b;
-    }
-}
-
-// End of a wave's tile range: every level's lattice leaves.
-__device__ __forceinline__ void field_scatter_lattice_finish(LatState &st, const NsrLevel *__restrict__ lds_lv,
-                                                             float4 *__restrict__ lat, float *__restrict__ gt, int lane, bool td, bool tc) {
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll 1
-    for (int fl = 0; fl < 16; fl++) lat_flush_dispatch(lat, fl, st, lds_lv, gt, lane, td, tc);
-    st.b0 = st.b1 = st.b2 = LAT_NONE;
-}
-
 // FEATS: the forward saved the encoder outputs (the default).  Compile-time because the re-gather path, though
 // never executed then, costs the one-wave-per-SIMD kernel registers and schedule (measured 20.1 vs 20.4-22 ms).
-// SORTED: the samples are walked through FieldArgs::perm (nsr_sample_order) and scattered by the lattice accumulator;
-// otherwise in buffer (ray) order by the sequential run tracker.
-template <typename TT, int CD, bool FEATS, bool SORTED>
+// GOUT: instead of scattering, the per-level encoder gradients of every sample are written to FieldBwdArgs::gout
+// (256 B/sample) for the stand-alone, high-occupancy table scatter (table_scatter.hip) that walks the samples in
+// nsr_sample_order's spatial order.  This kernel runs one wave per SIMD (its 240 weight-gradient accumulators): the
+// scatter's dependent LDS / atomic chains are exactly what one wave per SIMD cannot hide.
+template <typename TT, int CD, bool FEATS, bool GOUT>
 __global__ void __launch_bounds__(BWD_THREADS)
 k_field_bwd(FieldBwdArgs b) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -579,11 +367,7 @@ k_field_bwd(FieldBwdArgs b) {
     const FieldArgs &a = b.f;
     field_build_fw<CD, false>(wl, a.params);
     field_build_bw<CD>(wt, a.params);
-    if (threadIdx.x < 16) {
-        NsrLevel v = a.lv[threadIdx.x];
-        if (SORTED) v.pad_ = (uint32_t)b.lat.S[threadIdx.x] | ((uint32_t)b.lat.base[threadIdx.x] << 8);
-        lds_lv[threadIdx.x] = v;
-    }
+    if (threadIdx.x < 16) lds_lv[threadIdx.x] = a.lv[threadIdx.x];
     __syncthreads();
 
     const uint32_t Mc = a.m_dev ? min((uint32_t)max(a.m_dev[0], 0), a.M) : a.M;
@@ -600,15 +384,9 @@ k_field_bwd(FieldBwdArgs b) {
     const int nc = (int)b.nc;
     ScatterQueue q;
     q.rows = nullptr; q.vals = nullptr; q.head = q.tail = 0;
-    char *qbase_g;
-    float4 *lat = nullptr;
+    char *qbase_g = nullptr;
     char *const wave_lds = smem + (size_t)(FW_TOTAL + BW_TOTAL) * 2 + 16 * sizeof(NsrLevel);
-    if (SORTED) {
-        char *base = wave_lds + (size_t)wave * BWD_LAT_BYTES_PER_WAVE;
-        lat = reinterpret_cast<float4 *>(base);
-        qbase_g = base + (size_t)LAT_MAX_SLOTS * 16 + 256;
-        for (int k = lane; k < LAT_MAX_SLOTS; k += 64) lat[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-    } else {
+    if (!GOUT) {
         char *qbase = wave_lds + (size_t)wave * BWD_QUEUE_BYTES_PER_WAVE;
         q.vals = reinterpret_cast<float4 *>(qbase);
         q.rows = reinterpret_cast<uint32_t *>(qbase + SCQ_CAP * 16);
@@ -619,10 +397,6 @@ k_field_bwd(FieldBwdArgs b) {
     seq.c0 = seq.c1 = seq.c2 = 0x7FFFFFF0u;
     seq.kA = seq.kB = 0u;
     seq.aA = seq.aB = make_float4(0.f, 0.f, 0.f, 0.f);
-    LatState latst;
-    latst.b0 = latst.b1 = latst.b2 = LAT_NONE;
-    uint32_t lat_key = LAT_NONE;
-    const uint32_t lat_myS = SORTED ? (lds_lv[lane >> 2].pad_ & 0xFFu) : 0u, lat_mybase = SORTED ? (lds_lv[lane >> 2].pad_ >> 8) : 0u;
     float4 *const seqG = reinterpret_cast<float4 *>(qbase_g);        // [16 levels][16 samples] float4 staging, 4 KB
     const bool td = b.train_density != 0, tc = b.train_color != 0;
     float *const gt1 = b.grad_tables - 4;      // ring rows are stored +1 (field_scatter_level)
@@ -653,12 +427,8 @@ k_field_bwd(FieldBwdArgs b) {
         float grgb[4];     // grad_rgbs[m, 4g .. 4g+3]
     };
     // position `16 * tile + s` of the walk -> index into the sample buffers (0 for lanes past the count)
-    // (SORTED: one unconditional load -- a select between a loaded and a computed value would make the compiler wait
-    // for the load, and with it for every other load in flight, right where it is issued; lanes past the count read the
-    // last valid entry and are masked where the data is used.  The launcher guarantees perm != NULL for SORTED kernels.)
     auto fetch_idx = [&](uint32_t tile) -> uint32_t {
         const uint32_t m = tile * 16 + s;
-        if (SORTED) return a.perm[min(m, Mc - 1u)];
         return m < Mc ? m : 0u;
     };
     auto load_tile = [&](uint32_t tile, uint32_t buf_idx) {
@@ -689,13 +459,21 @@ k_field_bwd(FieldBwdArgs b) {
     const uint32_t wchunk = (t_end > t_begin ? (t_end - t_begin + BWD_THREADS / 64 - 1) / (BWD_THREADS / 64) : 0u);
     const uint32_t w_begin = min(t_begin + wave * wchunk, t_end), w_end = min(w_begin + wchunk, t_end);
     TileIn cur;
-    // SORTED: the permutation entry of a tile is fetched one tile ahead of its data, so that no load in the steady
-    // state depends on a load issued in the same batch
-    uint32_t idx_next = 0;
-    if (w_begin < w_end) {
-        cur = load_tile(w_begin, fetch_idx(w_begin));
-        if (w_begin + 1 < w_end) idx_next = fetch_idx(w_begin + 1);
-    }
+    if (w_begin < w_end) cur = load_tile(w_begin, fetch_idx(w_begin));
+    // GOUT: one tile's per-level encoder gradients, 4 x 16 bytes per lane = 256 contiguous bytes per sample ([16][4] floats)
+    float4 gout_v[4];
+    uint32_t gout_m = 0;
+    bool gout_valid = false;
+    auto gout_store = [&]() {
+        if (gout_valid) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int lv_i = (i < 2 ? 2 * g : 8 + 2 * g) + (i & 1);
+                b.gout[(size_t)gout_m * 16 + lv_i] = gout_v[i];
+            }
+        }
+        gout_valid = false;
+    };
 
 #ifdef NSR_ABL_STATS
     unsigned long long tacc[4] = {0, 0, 0, 0};
@@ -714,6 +492,9 @@ k_field_bwd(FieldBwdArgs b) {
         NSR_TACC(0, tk0, tk1);
         const uint32_t m = tile * 16 + s;
         const bool valid = m < Mc;
+        // GOUT writes no LDS inside this loop, so the compiler would hoist the (loop-invariant) weight-fragment LDS reads
+        // out of it and spill them all -- 220 VGPRs to scratch, reloaded every tile.  The barrier keeps them where they are.
+        if (GOUT) asm volatile("" ::: "memory");
         const float u0 = valid ? field_unit(cur.x0, a.bmin[0], a.bsize[0]) : 0.f;
         const float u1 = valid ? field_unit(cur.x1, a.bmin[1], a.bsize[1]) : 0.f;
         const float u2 = valid ? field_unit(cur.x2, a.bmin[2], a.bsize[2]) : 0.f;
@@ -727,13 +508,14 @@ k_field_bwd(FieldBwdArgs b) {
         if (!FEATS) field_encode<TT, CD, false>(lds_lv, tables, u0, u1, u2, live, g, cur.xd, cur.xc, a.fast_levels);
 
         // paced drain of the previous tile's records: SCQ_PACE(n) issues <= n atomic wave-instructions
-#define SCQ_PACE(n) do { if (!SORTED) scq_pace(q, gt1, lane, td, tc, (n), false); } while (0)
+#define SCQ_PACE(n) do { if (!GOUT) scq_pace(q, gt1, lane, td, tc, (n), false); } while (0)
         // ================= recompute forward, keeping rounded activations ====================
         s8v xd[1] = {cur.xd}, xc[1] = {cur.xc};
         f4v h[4];
         s8v hd[2], hk[2], hc[2], hr1[2], hr2[2];
         f4v logit[1], c1[1], rgb[1];
         mm_layer32<CD, 4, 1>(wl + FW_D1, lane, xd, h);
+        if (GOUT) gout_store();            // the previous tile's encoder gradients: after this tile's inputs have been waited for
         mm_pack64<CD, true>(h, hd);
         mm_layer32<CD, 1, 2>(wl + FW_D2, lane, hd, logit);
         mm_layer32<CD, 4, 1>(wl + FW_K1, lane, xc, h);
@@ -865,15 +647,8 @@ k_field_bwd(FieldBwdArgs b) {
         // Next tile's loads go out BEFORE this tile's scatter: the scatter touches LDS only (its records are
         // turned into atomics by the pace points of the next tile), so by the next loop top both these loads
         // and the atomics issued ahead of them (vmcnt retires in order) have had the whole scatter to land.
-        // Both walks: the loads sit between the MLP section (whose registers are dead here) and the scatter.  SORTED: the
-        // permutation entry was fetched one tile ahead, so nothing here depends on a load of the same batch.  (Issuing
-        // these at the loop top instead -- a whole iteration of slack -- keeps 16 more registers live through the MLP
-        // section and spills: measured slower.)
         TileIn nxt = cur;
-        if (tile + 1 < w_end) {
-            nxt = load_tile(tile + 1, SORTED ? idx_next : fetch_idx(tile + 1));
-            if (SORTED && tile + 2 < w_end) idx_next = fetch_idx(tile + 2);
-        }
+        if (tile + 1 < w_end) nxt = load_tile(tile + 1, fetch_idx(tile + 1));
         NSR_TICK(tk3);
         NSR_TACC(3, tk2, tk3);
         if (td || tc) {
@@ -883,8 +658,14 @@ k_field_bwd(FieldBwdArgs b) {
                 const int t = i >> 1, e0 = 2 * (i & 1);
                 sg[i] = live ? make_float4(gxd[t][e0], gxd[t][e0 + 1], gxc[t][e0], gxc[t][e0 + 1]) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
-            if (SORTED) field_scatter_lattice(latst, lat_key, lds_lv, seqG, lat, b.grad_tables, u0, u1, u2, live, sg, lane, td, tc,
-                                              lat_myS, lat_mybase);
+            if (GOUT) {
+                // kept in registers over the loop edge and stored early in the NEXT tile (gout_store): a store issued here
+                // would be waited for -- one in-order vmcnt -- together with the next tile's loads at the loop top
+#pragma unroll
+                for (int i = 0; i < 4; i++) gout_v[i] = sg[i];
+                gout_m = m;
+                gout_valid = valid;
+            }
             else field_scatter_seq(seq, lds_lv, seqG, q, gt1, live ? u0 : 0.f, live ? u1 : 0.f, live ? u2 : 0.f, sg, lane, td, tc);
         }
         NSR_TICK(tk4);
@@ -894,9 +675,8 @@ k_field_bwd(FieldBwdArgs b) {
 #ifdef NSR_ABL_STATS
     for (int i = 0; i < 4; i++) NSR_STAT_ALWAYS(4 + i, tacc[i]);
 #endif
-    if (SORTED) {
-        if (td || tc) field_scatter_lattice_finish(latst, lds_lv, lat, b.grad_tables, lane, td, tc);
-    } else if (td || tc) {
+    if (GOUT) gout_store();
+    if (!GOUT && (td || tc)) {
         // close the runs still open in registers
         if (q.tail - q.head > SCQ_CAP - 128) scq_pace(q, gt1, lane, td, tc, 16, false);
         const bool fp[2] = {seq_nonzero(seq.aA), seq_nonzero(seq.aB)};
@@ -923,10 +703,14 @@ k_field_bwd(FieldBwdArgs b) {
 
 extern "C" {
 
+uint64_t nsr_field_backward_workspace_bytes(uint32_t M, int with_perm) {
+    return with_perm ? (uint64_t)M * 16 * sizeof(float4) : 0;        // the [M][16] float4 encoder-gradient buffer
+}
+
 int nsr_field_backward(const nsr_field_desc *desc, const void *tables, const float *mlp_params, const float *xyzs, uint32_t M,
                        const int32_t *m_dev, const float *grad_sigmas, const float *grad_rgbs, float *grad_tables,
                        float *grad_mlp, int train_density_table, int train_color_table, const void *feats,
-                       const uint32_t *perm, nsr_stream_t stream) {
+                       const uint32_t *perm, void *workspace, nsr_stream_t stream) {
     if (M == 0) return NSR_OK;
     NSR_CHECK_PTR(desc); NSR_CHECK_PTR(tables); NSR_CHECK_PTR(mlp_params); NSR_CHECK_PTR(xyzs);
     NSR_CHECK_PTR(grad_sigmas); NSR_CHECK_PTR(grad_rgbs);
@@ -944,9 +728,13 @@ int nsr_field_backward(const nsr_field_desc *desc, const void *tables, const flo
     b.f.tiles_per_block = (ntiles + nblocks - 1) / nblocks;
     b.f.tables = tables; b.f.params = mlp_params; b.f.xyzs = xyzs; b.f.m_dev = m_dev; b.f.sigmas = nullptr; b.f.rgbs = nullptr;
     b.f.feats = const_cast<void *>(feats);
-    b.f.perm = perm;
-    if (perm != nullptr) {
-        if (!lat_geometry(b.f.lv, b.lat)) return NSR_ERR_UNSUPPORTED;   // grid too fine for the 10-bit blocks: walk in buffer order
+    b.f.perm = nullptr;                         // this kernel always walks in buffer order; `perm` orders the table scatter
+    const bool gout = perm != nullptr && (train_density_table || train_color_table);
+    b.gout = nullptr;
+    if (gout) {
+        if (workspace == nullptr || ((uintptr_t)workspace & 15u)) return NSR_ERR_INVALID_ARG;
+        if (!nsr_table_scatter_supported(b.f.lv)) return NSR_ERR_UNSUPPORTED;   // grid too fine for the 10-bit blocks: call without perm
+        b.gout = (float4 *)workspace;
     }
     if (feats && ((uintptr_t)feats & 15u)) return NSR_ERR_INVALID_ARG;
     b.grad_sigmas = grad_sigmas; b.grad_rgbs = grad_rgbs; b.grad_tables = grad_tables; b.grad_mlp = grad_mlp;
@@ -980,11 +768,17 @@ int nsr_field_backward(const nsr_field_desc *desc, const void *tables, const flo
         }                                                                                                      \
         hipLaunchKernelGGL((k_field_bwd<TT, CD, FEATS, SORTED>), grid, block, (LDSB), s, b);                   \
         NSR_ABL_REPORT();                                                                                      \
-        return nsr_launch_status();                                                                            \
+        if (hipGetLastError() != hipSuccess) return NSR_ERR_LAUNCH;                                            \
+        if (SORTED) {                                                                                          \
+            /* second kernel: the table scatter in the permutation's order, many waves per CU */               \
+            return nsr_table_scatter_launch(b.f.lv, b.f.bmin, b.f.bsize, xyzs, perm, m_dev, M, workspace, grad_tables, \
+                                            train_density_table, train_color_table, s);                        \
+        }                                                                                                      \
+        return NSR_OK;                                                                                         \
     } while (0)
 #define NSR_BWD_LAUNCH(TT, CD, FEATS)                                                                          \
     do {                                                                                                       \
-        if (perm != nullptr) NSR_BWD_LAUNCH_(TT, CD, FEATS, true, BWD_LDS_BYTES_SORTED);                       \
+        if (gout) NSR_BWD_LAUNCH_(TT, CD, FEATS, true, BWD_LDS_BYTES);                                         \
         NSR_BWD_LAUNCH_(TT, CD, FEATS, false, BWD_LDS_BYTES);                                                  \
     } while (0)
     if (feats != nullptr) {                      // no gather in the kernel: the table type does not matter

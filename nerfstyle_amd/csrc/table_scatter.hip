@@ -1,0 +1,316 @@
+// Stand-alone table scatter of the fused field backward, gfx950 (the spatially ordered path).
+//
+// nsr_field_backward with a `perm` (nsr_sample_order) runs the MLP backward kernel in "gradients out" mode -- it writes
+// d loss / d (encoder output) of every sample, 256 B, instead of scattering -- and then THIS kernel, which walks the
+// samples in the permutation's spatial order and accumulates the table gradient.  Why two kernels: the MLP backward
+// needs one wave per SIMD (240 weight-gradient accumulators per lane), and the scatter is a chain of dependent LDS
+// round trips and atomics that one wave per SIMD cannot hide (measured fused: MLP 13.8 ms + scatter 32 ms on the bench
+// frame).  Here a wave needs ~64 registers and 11.5 KB of LDS, so ten of them share a CU.
+//
+// Lattice accumulator.  The order's key is the sample's BLOCK: its encoder input quantised to 10 bits per axis (a 4^3
+// group of finest-level cells for the reference's 16-level grid).  Consecutive samples -- of MANY rays -- share a block,
+// and a block touches only a handful of cells on every level: at most ceil(res_l / 1024) + 1 per axis.  So the wave
+// keeps, per level, a small LATTICE of corner gradients in LDS anchored at the cell of the block's origin (5^3 corners
+// on the two finest levels, 4^3 on the next two, 3^3 below: 702 float4 = 11 KB per wave).  Lane = (level l = lane >> 2,
+// y/z corner pair p = lane & 3) walks the samples in order and adds its two x corners' contributions with a plain LDS
+// read-modify-write: within a step the 64 lanes touch 128 different slots and steps are sequential, so no atomics are
+// needed; the lattice is addressed by cell coordinates, so nothing is hashed per sample.  When the walk enters a new
+// block every level re-anchors; a level whose anchor cell did not change (the coarse ones: a block is a fraction of
+// their cell) keeps accumulating, the others are flushed cooperatively, one merged record per corner a block touched
+// (tools/sorted_scatter_sim.py: ~6 records and ~3 atomic requests per sample on the bench scene against 29.7 / 19.3 of
+// the ray-order run tracker).
+#include "field_common.h"
+#include "table_scatter.h"
+
+#ifdef NSR_ABL_STATS
+#define NSR_STAT(i, n) do { } while (0)
+#else
+#define NSR_STAT(i, n) do { } while (0)
+#endif
+
+__device__ __forceinline__ bool seq_nonzero(const float4 &v) {
+    return ((__float_as_uint(v.x) | __float_as_uint(v.y) | __float_as_uint(v.z) | __float_as_uint(v.w)) << 1) != 0u;
+}
+
+struct LatGeom {
+    uint16_t base[16];      // first slot of the level's lattice
+    uint8_t S[16];          // corners per axis
+};
+constexpr int LAT_MAX_SLOTS = 1024;                  // float4 slots per wave (16 KB)
+constexpr int LAT_KEY_BITS = 10;                     // must match nsr_sample_order's quantisation
+constexpr uint32_t LAT_NONE = 0xFFFFFFFFu;
+struct LatState {
+    uint32_t b0, b1, b2;     // anchor cell of this lane's level (LAT_NONE: nothing accumulated yet)
+};
+
+// Host: lattice geometry for the 1/1024 blocks of the sample order.  A block spans e = res / 1024 cells of a level:
+// it touches at most floor(e) + 2 cells per axis (exactly e when the level's cells tile the block), one more corner.
+static bool lat_geometry(const NsrLevel *lv, LatGeom &g) {
+    uint32_t total = 0;
+    for (int l = 0; l < 16; l++) {
+        const uint32_t res = lv[l].resolution, blocks = 1u << LAT_KEY_BITS;
+        const uint32_t cells = (res % blocks == 0) ? res / blocks : res / blocks + 2;
+        const uint32_t S = cells + 1;
+        if (S > 6) return false;
+        g.S[l] = (uint8_t)S;
+        g.base[l] = (uint16_t)total;
+        total += S * S * S;
+    }
+    return total <= (uint32_t)LAT_MAX_SLOTS;
+}
+
+// Flushes level l's lattice, anchored at cell (b0, b1, b2) -- wave-uniform arguments -- and clears it.
+// 64 slots per trip, three phases so that nothing is computed four times and every LDS round trip is shared:
+//   1. one lane per slot: read its float4, test it, and (touched slots only) compute the table row ONCE -> rows[lane];
+//   2. four groups of 16 slots, skipped when empty: lane (t = lane >> 2, i = lane & 3) reads component i of slot
+//      16q + t and its row and issues the atomic -- the four dwords of a row leave as ONE 16-byte request, x-neighbouring
+//      corners (consecutive slots) share their 64-byte line;
+//   3. the touched slots are cleared.
+template <int S>
+__device__ __forceinline__ void lat_flush_level(float4 *__restrict__ lat4, uint32_t *__restrict__ rows, uint32_t b0, uint32_t b1, uint32_t b2,
+                                                const NsrLevel &lv, float *__restrict__ gt, int lane, bool td, bool tc) {
+    constexpr int NC = S * S * S;
+    const int t = lane >> 2, i = lane & 3;
+    const bool on = (i < 2) ? td : tc;
+    const float *lf = reinterpret_cast<const float *>(lat4);
+#pragma unroll
+    for (int k0 = 0; k0 < NC; k0 += 64) {
+        NSR_STAT(2, 1);
+        const int k = k0 + lane;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (k < NC) v = lat4[k];
+        const bool nz = seq_nonzero(v);
+        const unsigned long long m = __ballot(nz);
+        if (m == 0ull) continue;                                          // wave-uniform: nothing touched in these slots
+        if (nz) {
+            const int z = k / (S * S), r = k - z * (S * S), y = r / S, x = r - y * S;
+            rows[lane] = lv.offset + nsr_grid_row(lv, b0 + (uint32_t)x, b1 + (uint32_t)y, b2 + (uint32_t)z, 0u);
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            if (k0 + 16 * q >= NC) break;
+            if (((m >> (16 * q)) & 0xFFFFull) == 0ull) continue;          // wave-uniform
+            const bool rec = (m >> (16 * q + t)) & 1ull;
+            if (rec) {
+                const float val = lf[(k0 + 16 * q + t) * 4 + i];
+                const uint32_t row = rows[16 * q + t];
+#ifndef NSR_ABL_NO_ATOMIC
+                if (on) atomicAdd(gt + (size_t)row * 4 + i, val);
+#else
+                if (on && row == 0xFFFFFFFFu) gt[i] = val;
+#endif
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (nz) lat4[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+
+// The geometry of level fl comes from the LDS copy of the level table (pad_ = S | base << 8): a read from the
+// kernel-argument segment here would be a vector-memory load, and waiting for it means waiting for every atomic in flight.
+__device__ __forceinline__ void lat_flush_dispatch(float4 *__restrict__ lat, int fl, const LatState &st,
+                                                   const NsrLevel *__restrict__ lds_lv, float *__restrict__ gt, int lane, bool td, bool tc) {
+    const uint32_t o0 = (uint32_t)__builtin_amdgcn_readlane((int)st.b0, fl * 4);
+    if (o0 == LAT_NONE) return;
+    const uint32_t o1 = (uint32_t)__builtin_amdgcn_readlane((int)st.b1, fl * 4);
+    const uint32_t o2 = (uint32_t)__builtin_amdgcn_readlane((int)st.b2, fl * 4);
+    const NsrLevel flv = lds_lv[fl];
+    NSR_STAT(1, 1);
+    float4 *lf = lat + (flv.pad_ >> 8);
+    uint32_t *rows = reinterpret_cast<uint32_t *>(lat) - 64;                  // 64-entry row scratch in front of the lattices
+    switch (flv.pad_ & 0xFFu) {
+    case 3: lat_flush_level<3>(lf, rows, o0, o1, o2, flv, gt, lane, td, tc); break;
+    case 4: lat_flush_level<4>(lf, rows, o0, o1, o2, flv, gt, lane, td, tc); break;
+    case 5: lat_flush_level<5>(lf, rows, o0, o1, o2, flv, gt, lane, td, tc); break;
+    default: lat_flush_level<6>(lf, rows, o0, o1, o2, flv, gt, lane, td, tc); break;
+    }
+}
+
+
+struct TableScatterArgs {
+    const float *xyzs;
+    const uint32_t *perm;
+    const int32_t *m_dev;
+    uint32_t M;
+    const float4 *gin;            // [M][16] float4: d loss / d (density f0, f1, colour f0, f1) per level
+    float *grad_tables;
+    float bmin[3], bsize[3];
+    int td, tc;
+    uint32_t lat_slots;           // float4 slots per wave (multiple of 64)
+    NsrLevel lv[16];              // pad_ = S | base << 8
+};
+
+constexpr int TS_THREADS = 128;
+static size_t ts_wave_bytes(uint32_t lat_slots) { return 256 + (size_t)lat_slots * 16; }
+
+__global__ void __launch_bounds__(TS_THREADS)
+k_table_scatter(TableScatterArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    NsrLevel *lds_lv = reinterpret_cast<NsrLevel *>(smem);
+    if (threadIdx.x < 16) lds_lv[threadIdx.x] = a.lv[threadIdx.x];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    char *base = smem + 16 * sizeof(NsrLevel) + (size_t)wave * (256 + (size_t)a.lat_slots * 16);
+    float4 *lat = reinterpret_cast<float4 *>(base + 256);               // the 64-entry row scratch sits in front of it
+    for (uint32_t k = lane; k < a.lat_slots; k += 64) lat[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
+
+    const uint32_t Mc = a.m_dev ? min((uint32_t)max(a.m_dev[0], 0), a.M) : a.M;
+    if (Mc == 0) return;
+    const uint32_t ntiles = (Mc + 15) / 16;
+    const uint32_t nwaves = gridDim.x * (TS_THREADS / 64), gw = blockIdx.x * (TS_THREADS / 64) + wave;
+    const uint32_t per = (ntiles + nwaves - 1) / nwaves;
+    const uint32_t w_begin = min(gw * per, ntiles), w_end = min(w_begin + per, ntiles);
+    if (w_begin >= w_end) return;
+    const int s = lane & 15;
+    const int l = lane >> 2, py = lane & 1, pz = (lane >> 1) & 1;
+    const NsrLevel lv = lds_lv[l];
+    const uint32_t S = lv.pad_ & 0xFFu;
+    float4 *const mylat = lat + (lv.pad_ >> 8) + ((uint32_t)pz * S + (uint32_t)py) * S;
+    const bool td = a.td != 0, tc = a.tc != 0;
+    float *const gt = a.grad_tables;
+    const float kq = (float)(1 << LAT_KEY_BITS), rk = 1.0f / kq;
+    LatState st;
+    st.b0 = st.b1 = st.b2 = LAT_NONE;
+    uint32_t cur_key = LAT_NONE;
+
+    // position 16 * tile + s of the order -> buffer index; lanes past the count read the last valid entry (masked later)
+    auto fetch_idx = [&](uint32_t tile) -> uint32_t { return a.perm[min(tile * 16 + (uint32_t)s, Mc - 1u)]; };
+    uint32_t idx = fetch_idx(w_begin);
+    uint32_t idx_next = w_begin + 1 < w_end ? fetch_idx(w_begin + 1) : idx;
+    float x0 = a.xyzs[(size_t)idx * 3], x1 = a.xyzs[(size_t)idx * 3 + 1], x2 = a.xyzs[(size_t)idx * 3 + 2];
+
+    for (uint32_t tile = w_begin; tile < w_end; tile++) {
+        // next tile's inputs: the permutation entry was fetched one tile ahead, so these loads depend on nothing in flight
+        float nx0 = x0, nx1 = x1, nx2 = x2;
+        uint32_t idx_nn = idx_next;
+        if (tile + 1 < w_end) {
+            nx0 = a.xyzs[(size_t)idx_next * 3]; nx1 = a.xyzs[(size_t)idx_next * 3 + 1]; nx2 = a.xyzs[(size_t)idx_next * 3 + 2];
+            if (tile + 2 < w_end) idx_nn = fetch_idx(tile + 2);
+        }
+        const bool valid = tile * 16 + (uint32_t)s < Mc;
+        const float u0 = field_unit(x0, a.bmin[0], a.bsize[0]), u1 = field_unit(x1, a.bmin[1], a.bsize[1]),
+                    u2 = field_unit(x2, a.bmin[2], a.bsize[2]);
+        const bool live = valid && (u0 >= 0 && u0 <= 1 && u1 >= 0 && u1 <= 1 && u2 >= 0 && u2 <= 1);
+        const uint32_t live16 = (uint32_t)(__ballot(live) & 0xFFFFull);      // lanes 0..15 are samples 0..15
+        // this lane's sample's block: the sort key's quantisation (sample_order.hip), 10 bits per axis
+        const uint32_t q0 = (uint32_t)fminf(fmaxf(u0 * kq, 0.0f), kq - 1.0f), q1 = (uint32_t)fminf(fmaxf(u1 * kq, 0.0f), kq - 1.0f),
+                       q2 = (uint32_t)fminf(fmaxf(u2 * kq, 0.0f), kq - 1.0f);
+        const uint32_t bkey = q0 | (q1 << LAT_KEY_BITS) | (q2 << (2 * LAT_KEY_BITS));
+        // the per-level gradients of a sample are fetched one step ahead of their use
+        float4 gr_next = a.gin[(size_t)(uint32_t)__builtin_amdgcn_readlane((int)idx, 0) * 16 + l];
+#pragma unroll 2
+        for (int step = 0; step < 16; step++) {
+            const float4 gr = gr_next;
+            if (step < 15) gr_next = a.gin[(size_t)(uint32_t)__builtin_amdgcn_readlane((int)idx, step + 1) * 16 + l];
+            if (!((live16 >> step) & 1u)) continue;                            // wave-uniform
+            const uint32_t key = (uint32_t)__builtin_amdgcn_readlane((int)bkey, step);
+            if (key != cur_key) {
+                // ---- the walk enters another block: re-anchor every level at the cell of the block's origin ----
+                cur_key = key;
+                const float o0 = (float)(key & ((1u << LAT_KEY_BITS) - 1u)) * rk, o1 = (float)((key >> LAT_KEY_BITS) & ((1u << LAT_KEY_BITS) - 1u)) * rk,
+                            o2 = (float)(key >> (2 * LAT_KEY_BITS)) * rk;
+                float ff;
+                uint32_t n0, n1, n2;
+                nsr_grid_locate(o0, lv.resolution, 1, ff, n0);
+                nsr_grid_locate(o1, lv.resolution, 1, ff, n1);
+                nsr_grid_locate(o2, lv.resolution, 1, ff, n2);
+                const bool chg = (n0 != st.b0) | (n1 != st.b1) | (n2 != st.b2);
+                unsigned long long mm = __ballot(chg);
+                while (mm) {
+                    const int fl = (int)(__builtin_ctzll(mm) >> 2);
+                    mm &= ~(0xFull << (fl * 4));
+                    lat_flush_dispatch(lat, fl, st, lds_lv, gt, lane, td, tc);
+                }
+                if (chg) { st.b0 = n0; st.b1 = n1; st.b2 = n2; }
+            }
+            const float su0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, u0), step));
+            const float su1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, u1), step));
+            const float su2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, u2), step));
+            float f0, f1, f2;
+            uint32_t c0, c1, c2;
+            nsr_grid_locate(su0, lv.resolution, 1, f0, c0);
+            nsr_grid_locate(su1, lv.resolution, 1, f1, c1);
+            nsr_grid_locate(su2, lv.resolution, 1, f2, c2);
+            // cell relative to the anchor: 0 .. S - 2 by construction (the sample lies in the block the anchor was taken
+            // from; floor(u * res) is monotonic in u)
+            const uint32_t d0 = c0 - st.b0, d1 = c1 - st.b1, d2 = c2 - st.b2;
+            const uint32_t r0 = min(d0, S - 2u), r1 = min(d1, S - 2u), r2 = min(d2, S - 2u);
+            // this sample's contribution to the lane's two x corners: (wx*wy)*wz, the product order of the forward
+            const float wy = py ? f1 : 1 - f1, wz = pz ? f2 : 1 - f2;
+            float wA = ((1 - f0) * wy) * wz, wB = (f0 * wy) * wz;
+            if (max(d0, max(d1, d2)) > S - 2u) {
+                // fp32 rounding put the cell one past the lattice (u * res of a sample at the very end of its block can
+                // round up across a cell boundary that the block's real extent stops short of): this sample's two corners
+                // go straight to the table, exactly; the (clamped) lattice slots get nothing
+                const uint32_t rowA = lv.offset + nsr_grid_row(lv, c0, c1 + (uint32_t)py, c2 + (uint32_t)pz, 0u);
+                const uint32_t rowB = lv.offset + nsr_grid_row(lv, c0 + 1u, c1 + (uint32_t)py, c2 + (uint32_t)pz, 0u);
+                const float ga[4] = {gr.x, gr.y, gr.z, gr.w};
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    if ((i < 2 ? td : tc) && ga[i] != 0.0f) {
+                        atomicAdd(gt + (size_t)rowA * 4 + i, wA * ga[i]);
+                        atomicAdd(gt + (size_t)rowB * 4 + i, wB * ga[i]);
+                    }
+                }
+                wA = 0.0f;
+                wB = 0.0f;
+            }
+            float4 *const slot = mylat + ((r2 * S + r1) * S + r0);
+            float4 va = slot[0], vb = slot[1];
+            va.x = fmaf(wA, gr.x, va.x); va.y = fmaf(wA, gr.y, va.y); va.z = fmaf(wA, gr.z, va.z); va.w = fmaf(wA, gr.w, va.w);
+            vb.x = fmaf(wB, gr.x, vb.x); vb.y = fmaf(wB, gr.y, vb.y); vb.z = fmaf(wB, gr.z, vb.z); vb.w = fmaf(wB, gr.w, vb.w);
+            slot[0] = va;
+            slot[1] = vb;
+        }
+        x0 = nx0; x1 = nx1; x2 = nx2;
+        idx = idx_next;
+        idx_next = idx_nn;
+    }
+    // every level's lattice leaves
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll 1
+    for (int fl = 0; fl < 16; fl++) lat_flush_dispatch(lat, fl, st, lds_lv, gt, lane, td, tc);
+}
+
+bool nsr_table_scatter_supported(const NsrLevel *lv) {
+    LatGeom g;
+    return lat_geometry(lv, g);
+}
+
+int nsr_table_scatter_launch(const NsrLevel *levels, const float *bmin, const float *bsize, const float *xyzs, const uint32_t *perm,
+                             const int32_t *m_dev, uint32_t M, const void *gin, float *grad_tables, int td, int tc, hipStream_t s) {
+    TableScatterArgs a;
+    LatGeom g;
+    if (!lat_geometry(levels, g)) return NSR_ERR_UNSUPPORTED;
+    uint32_t total = 0;
+    for (int l = 0; l < 16; l++) {
+        a.lv[l] = levels[l];
+        a.lv[l].pad_ = (uint32_t)g.S[l] | ((uint32_t)g.base[l] << 8);
+        total = g.base[l] + (uint32_t)g.S[l] * g.S[l] * g.S[l];
+    }
+    a.lat_slots = (total + 63u) & ~63u;
+    a.xyzs = xyzs; a.perm = perm; a.m_dev = m_dev; a.M = M; a.gin = (const float4 *)gin; a.grad_tables = grad_tables;
+    for (int i = 0; i < 3; i++) { a.bmin[i] = bmin[i]; a.bsize[i] = bsize[i]; }
+    a.td = td; a.tc = tc;
+    const size_t lds = 16 * sizeof(NsrLevel) + (TS_THREADS / 64) * ts_wave_bytes(a.lat_slots);
+    static bool attr_set[64] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (!attr_set[dev & 63]) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_table_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, 65536) != hipSuccess)
+            return NSR_ERR_LAUNCH;
+        attr_set[dev & 63] = true;
+    }
+    if (lds > 65536) return NSR_ERR_UNSUPPORTED;
+    // as many workgroups as fit: LDS-bound (about five 2-wave workgroups per CU); each wave walks a contiguous run of tiles
+    uint32_t per_cu = (uint32_t)(160u * 1024u / lds);
+    if (per_cu > 8) per_cu = 8;
+    if (per_cu == 0) per_cu = 1;
+    uint32_t nblocks = 256u * per_cu;
+    const uint32_t ntiles = (M + 15) / 16;
+    if (nblocks > (ntiles + 1) / 2) nblocks = (ntiles + 1) / 2;
+    if (nblocks == 0) nblocks = 1;
+    hipLaunchKernelGGL(k_table_scatter, dim3(nblocks), dim3(TS_THREADS), lds, s, a);
+    return nsr_launch_status();
+}

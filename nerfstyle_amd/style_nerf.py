@@ -89,7 +89,7 @@ class _field(Function):
             feats = torch.empty(((M + 15) // 16) * 512, dtype=torch.int32, device=dev)
         with profiling.timed('field_fwd_sigma' if sigma_only else 'field_fwd'):
             L.check(L.lib().nsr_field_forward(ctypes.byref(desc), L.p(tables), L.p(model._mlp_flat()),
-                                              L.p(xyzs), M, L.p(m_dev), L.p(sigmas), L.p(rgbs), L.p(feats), L.p(perm),
+                                              L.p(xyzs), M, L.p(m_dev), L.p(sigmas), L.p(rgbs), L.p(feats), None,
                                               L.stream()),
                     'field_forward')
         ctx.feats = feats
@@ -119,12 +119,16 @@ class _field(Function):
         desc = model._desc(ctx.density_scale)
         ga = model.grad_arena
         tables = model._gather_tables()
+        ws = None
+        if ctx.perm is not None:
+            # [M][16] float4 of per-level encoder gradients for the spatially ordered table scatter (second kernel)
+            ws = torch.empty(int(L.lib().nsr_field_backward_workspace_bytes(M, 1)) // 4, dtype=torch.float32, device=dev)
         with profiling.timed('field_bwd'):
             L.check(L.lib().nsr_field_backward(
                 ctypes.byref(desc), L.p(tables), L.p(model._mlp_flat()), L.p(xyzs), M, L.p(ctx.m_dev),
                 L.p(grad_sigmas), L.p(grad_rgbs), L.p(ga), ga.data_ptr() + model.table_elems * 4,
-                int(model.train_density_table), int(model.train_color_table), L.p(ctx.feats), L.p(ctx.perm), L.stream()),
-                'field_backward')
+                int(model.train_density_table), int(model.train_color_table), L.p(ctx.feats), L.p(ctx.perm), L.p(ws),
+                L.stream()), 'field_backward')
         return None, None, None, None, None, None, None, None
 
 
@@ -317,8 +321,9 @@ class StyleTCNerf(nn.Module):
 
     # ---- forward -------------------------------------------------------------------------------
     def field(self, pts, sigma_only=False, m_dev=None, density_scale=1.0, perm=None):
-        """Fast path: flat sigmas [M] (and rgbs [M,3+nc]); m_dev = device int32 sample count; perm = spatial processing
-        order from `sample_order` (int32/uint32 [M] device tensor) -- same results, cache- and atomic-friendlier."""
+        """Fast path: flat sigmas [M] (and rgbs [M,3+nc]); m_dev = device int32 sample count; perm = spatial order from
+        `sample_order` (int32 [M] device tensor): the backward then accumulates the table gradient in that order with the
+        stand-alone lattice scatter kernel (same result up to fp32 summation order; pays on dense full-frame batches)."""
         want_feats = bool(self.save_features and torch.is_grad_enabled() and self.arena.requires_grad and not sigma_only)
         return _field.apply(pts, self.arena, self, sigma_only, m_dev, density_scale, want_feats, perm)
 
