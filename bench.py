@@ -58,7 +58,8 @@ def parse():
     ap.add_argument('--samples-cap', type=int, default=160, help='sample-buffer capacity in samples per ray')
     ap.add_argument('--sparsity-lambda', type=float, default=0.0, help='cfgs: --sparsity_lambda (0.01 in BASELINE configs[3])')
     ap.add_argument('--no-occ-update', action='store_true', help='leave the periodic occupancy update out of the step')
-    ap.add_argument('--sort-samples', action='store_true', help='walk the field kernels in nsr_sample_order order')
+    ap.add_argument('--sort-samples', choices=['auto', 'on', 'off'], default='auto',
+                    help="spatially ordered table scatter in the backward (nsr_sample_order): 'auto' = dense batches (>= 200 000 rays) only")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--graph', action='store_true',
                     help='replay the render+loss+backward part of the step as one captured hipGraph (small-batch series)')
@@ -167,7 +168,7 @@ def build(args, dev, rank):
     else:
         r.pin_march_bitfield(scene_bits)
         r.update_occ = True
-    r.sort_samples = bool(args.sort_samples)
+    r.sort_samples = {'auto': 'auto', 'on': True, 'off': False}[args.sort_samples]
     return model, r, rcfg, torch.tensor(poses_np, device=dev), intr
 
 
@@ -179,7 +180,8 @@ def profile_traffic(args):
             pm = json.load(f)
     except (OSError, ValueError):
         return None
-    if not (args.table_dtype == 'f16' and args.compute_dtype == 'f16' and args.stage == 'recon' and not args.sort_samples):
+    if not (args.table_dtype == 'f16' and args.compute_dtype == 'f16' and args.stage == 'recon' and args.sort_samples == 'auto'
+            and args.rays_per_gpu >= 1008 * 756 and args.scene == 'room' and args.sparsity_lambda == 0):
         return None
     return pm
 
@@ -274,9 +276,6 @@ def run_recon(args, dev, rank, world):
 
     for it in range(args.warmup):
         step(it)
-    if args.sort_samples and args.warmup > 0:
-        # host estimate of the emitted count (read OUTSIDE the timed region) so the capacity buffer is not sorted whole
-        r.sort_prefix_hint = int(int(total_samples.item()) / args.warmup * 1.15)
     total_samples.zero_()
     overflow.zero_()
     occ_before = int(r._occ_state[0]) if getattr(r, '_occ_state', None) is not None else 0
@@ -314,15 +313,19 @@ def run_recon(args, dev, rank, world):
     bytes_per_sample = {'field_fwd': 512 * tb, 'field_bwd': 2 * 512 * tb}
     pm = profile_traffic(args)
 
+    sorted_bwd = r.sort_samples is True or (r.sort_samples == 'auto' and n_rays >= r.sort_min_rays)
+    kernel_names = {'field_fwd': ['k_field_fwd'],
+                    'field_bwd': ['k_field_bwd', 'k_table_scatter'] if sorted_bwd else ['k_field_bwd']}
+
     def roof(name, launches, avg_ms):
         per_launch = bytes_per_sample[name] * samples / max(launches, 1)
         ach = per_launch / (avg_ms * 1e-3) / 1e9
-        d = {'bound': 'hbm', 'kernel': 'k_' + name, 'achieved': round(ach, 1), 'peak': 8000.0, 'unit': 'GB/s',
+        d = {'bound': 'hbm', 'kernel': ' + '.join(kernel_names[name]), 'achieved': round(ach, 1), 'peak': 8000.0, 'unit': 'GB/s',
              'frac': round(ach / 8000.0, 4), 'traffic': None, 'avg_launch_ms': round(avg_ms, 4),
              'algorithmic_bytes_per_sample': bytes_per_sample[name], 'samples_per_launch': int(samples / max(launches, 1))}
-        k = pm['kernels'].get('k_' + name) if pm else None
-        if k:
-            d['traffic'] = int(k['traffic_bytes_per_sample'] * samples / max(launches, 1))
+        ks = [pm['kernels'].get(kn) for kn in kernel_names[name]] if pm else []
+        if ks and all(ks):
+            d['traffic'] = int(sum(k['traffic_bytes_per_sample'] for k in ks) * samples / max(launches, 1))
             d['traffic_source'] = ('NOT measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command in '
                                    'profiles/{} (per-sample figure x this run\'s samples per launch)'.format(os.path.basename(PROFILE_JSON)))
             d['profile_commit'] = pm.get('commit')
@@ -342,13 +345,14 @@ def run_recon(args, dev, rank, world):
             extra['mlp_mfma_fwd'] = {'bound': 'mfma', 'kernel': 'k_field_fwd', 'achieved': round(tf, 1), 'peak': 2500.0,
                                      'unit': 'TFLOP/s', 'frac': round(tf / 2500.0, 4),
                                      'note': 'MLP FLOPs of the fused kernel over its whole duration (gather-bound kernel)'}
-        k = pm['kernels'].get('k_field_bwd') if pm else None
+        k = pm['kernels'].get('k_table_scatter' if sorted_bwd else 'k_field_bwd') if pm else None
         if 'field_bwd' in prof and k and k.get('atomic_requests_per_sample'):
             # what k_field_bwd actually queues on: memory-side float-atomic requests (TCC_EA0_ATOMIC per sample from the PMC
             # pass in profiles/) against the chip-wide rate tools/atomic_footprint_bench.hip measures
             launches, tot_ms, avg_ms = prof['field_bwd']
             rate = k['atomic_requests_per_sample'] * samples / max(launches, 1) / (avg_ms * 1e-3) / 1e9
-            extra['atomic_requests_bwd'] = {'bound': 'memory-side atomic unit', 'kernel': 'k_field_bwd', 'achieved': round(rate, 2),
+            extra['atomic_requests_bwd'] = {'bound': 'memory-side atomic unit', 'kernel': 'k_table_scatter' if sorted_bwd else 'k_field_bwd',
+                                            'achieved': round(rate, 2),
                                             'peak': 21.06, 'unit': 'G requests/s', 'frac': round(rate / 21.06, 4),
                                             'requests_per_sample': k['atomic_requests_per_sample'],
                                             'source': 'requests/sample from profiles/ (not this run); peak = measured microbenchmark'}
@@ -381,7 +385,8 @@ def run_recon(args, dev, rank, world):
             'occupancy': ('device-side update every {} steps inside the step (full update: {} sigma queries); the march reads the seeded '
                           'synthetic bitfield (random-init model has no scene)'.format(rcfg.update_iter, r.cascade * rcfg.grid_size ** 3)
                           if not args.no_occ_update else 'fixed synthetic bitfield, no update'),
-            'sample_order': 'nsr_sample_order (Morton blocks)' if args.sort_samples else 'ray order',
+            'table_scatter': ('spatial order (nsr_sample_order + stand-alone lattice scatter kernel)'
+                              if (r.sort_samples is True or (r.sort_samples == 'auto' and n_rays >= r.sort_min_rays)) else 'ray order (run tracker, fused)'),
             'sample_capacity_overflows': int(overflow.item()), 'final_loss': float(loss.detach()) / loss_scale * world,
         },
         'kernel_ms_per_step': {k: round(v[1] / args.steps, 4) for k, v in sorted(prof.items())},

@@ -141,7 +141,13 @@ struct TableScatterArgs {
     NsrLevel lv[16];              // pad_ = S | base << 8
 };
 
-constexpr int TS_THREADS = 128;
+#ifndef NSR_TS_THREADS
+#define NSR_TS_THREADS 256        /* measured on the bench frame: 64 -> 35.6 ms, 128 -> 30.6, 256 -> 29.4 (A + B) */
+#endif
+#ifndef NSR_TS_UNROLL
+#define NSR_TS_UNROLL 4         /* 1 -> 31.7 ms, 2 -> 30.6, 4 -> 29.4, 8 -> 29.6 */
+#endif
+constexpr int TS_THREADS = NSR_TS_THREADS;
 static size_t ts_wave_bytes(uint32_t lat_slots) { return 256 + (size_t)lat_slots * 16; }
 
 __global__ void __launch_bounds__(TS_THREADS)
@@ -199,7 +205,7 @@ k_table_scatter(TableScatterArgs a) {
         const uint32_t bkey = q0 | (q1 << LAT_KEY_BITS) | (q2 << (2 * LAT_KEY_BITS));
         // the per-level gradients of a sample are fetched one step ahead of their use
         float4 gr_next = a.gin[(size_t)(uint32_t)__builtin_amdgcn_readlane((int)idx, 0) * 16 + l];
-#pragma unroll 2
+#pragma unroll NSR_TS_UNROLL
         for (int step = 0; step < 16; step++) {
             const float4 gr = gr_next;
             if (step < 15) gr_next = a.gin[(size_t)(uint32_t)__builtin_amdgcn_readlane((int)idx, step + 1) * 16 + l];
@@ -303,13 +309,13 @@ int nsr_table_scatter_launch(const NsrLevel *levels, const float *bmin, const fl
         attr_set[dev & 63] = true;
     }
     if (lds > 65536) return NSR_ERR_UNSUPPORTED;
-    // as many workgroups as fit: LDS-bound (about five 2-wave workgroups per CU); each wave walks a contiguous run of tiles
+    // as many workgroups as fit: LDS-bound (three 4-wave workgroups per CU = 3 waves per SIMD); each wave walks a contiguous run of tiles
     uint32_t per_cu = (uint32_t)(160u * 1024u / lds);
     if (per_cu > 8) per_cu = 8;
     if (per_cu == 0) per_cu = 1;
     uint32_t nblocks = 256u * per_cu;
     const uint32_t ntiles = (M + 15) / 16;
-    if (nblocks > (ntiles + 1) / 2) nblocks = (ntiles + 1) / 2;
+    if (nblocks > (ntiles + 3) / 4) nblocks = (ntiles + 3) / 4;
     if (nblocks == 0) nblocks = 1;
     hipLaunchKernelGGL(k_table_scatter, dim3(nblocks), dim3(TS_THREADS), lds, s, a);
     return nsr_launch_status();

@@ -40,10 +40,13 @@ class Renderer(torch.nn.Module):
         self.update_occ = True
         self.bound = bound
         self.samples_per_ray_cap = samples_per_ray_cap
-        # Optional spatial processing order of the field kernels (nsr_sample_order): OFF by default.  Measured on the bench
-        # workload: forward 8.3 -> 8.2 ms, backward 49.3 -> 48.4 ms, sort 1.8 ms -- no net gain yet.
-        self.sort_samples = False
-        self.sort_prefix_hint = None     # estimate of the emitted sample count (host int) so a capacity buffer is not sorted whole
+        # Spatially ordered table scatter in the backward (nsr_sample_order + the two-kernel nsr_field_backward).  'auto': for
+        # dense batches only -- on a full 1008x756 frame the backward drops from 49 to 29 ms (+ 1.8 ms sort); on sparse random
+        # batches the blocks hold too few samples (65 536 random rays: 6.2 vs 4.5 ms).  True / False force it.
+        self.sort_samples = 'auto'
+        self.sort_min_rays = 200000
+        self.sort_prefix_hint = None     # estimate of the emitted sample count (host int) so a capacity buffer is not sorted whole;
+        self._count_probe = None         # None = maintained here from the previous calls' counts, read back without blocking
         self._pinned_bitfield = None
         self.aabb = torch.tensor([-bound, -bound, -bound, bound, bound, bound], dtype=torch.float32)
         self.cascade = 1 + ceil(log2(bound))
@@ -213,7 +216,9 @@ class Renderer(torch.nn.Module):
         xyzs, _, deltas, rays_info = raymarching.march_rays_train_nosync(
             rays.origins, rays.dirs, self.bound, self.march_bitfield, self.cascade, self.cfg.grid_size, nears, fars,
             M, counter, 0., self.cfg.max_steps)
-        perm = self.model.sample_order(xyzs, counter, self.sort_prefix_hint) if self.sort_samples else None
+        perm = None
+        if torch.is_grad_enabled() and (self.sort_samples is True or (self.sort_samples == 'auto' and N >= self.sort_min_rays)):
+            perm = self.model.sample_order(xyzs, counter, self._sort_prefix(M, counter))
         sigmas, rgbs = self.model.field(xyzs, sigma_only=False, m_dev=counter, density_scale=self.cfg.density_scale, perm=perm)
         weights_sum, depth, image = _composite_train_nosync(sigmas, rgbs, deltas, rays_info, self.cfg.t_thresh)
         classes = image[:, 3:]
@@ -221,6 +226,34 @@ class Renderer(torch.nn.Module):
         image = image + (1 - weights_sum).unsqueeze(-1)
         depth = torch.clamp(depth - nears, min=0) / (fars - nears)
         return image, depth, classes
+
+    def _sort_prefix(self, M: int, counter: torch.Tensor) -> int:
+        """How many leading slots of the capacity-sized sample buffer take part in the sort: an estimate of the emitted count
+        (any value is correct, see nsr_sample_order).  The count of an earlier call is copied to pinned host memory
+        asynchronously and picked up once its event has completed -- the step never waits for it."""
+        if self.sort_prefix_hint is not None:
+            return min(int(self.sort_prefix_hint), M)
+        if torch.cuda.is_current_stream_capturing():
+            return M                     # no event queries / host copies inside a graph capture
+        est = M
+        probe = self._count_probe
+        if probe is not None:
+            host, ev, last = probe
+            if ev is not None and ev.query():
+                last = int(host[0])
+                ev = None
+            if last is not None:
+                est = min(M, int(last * 1.15) + 65536)
+            self._count_probe = (host, ev, last)
+        if self._count_probe is None or self._count_probe[1] is None:
+            host = self._count_probe[0] if self._count_probe is not None else torch.zeros(2, dtype=torch.int32).pin_memory()
+            last = self._count_probe[2] if self._count_probe is not None else None
+            # enqueue AFTER the march of this call has written the counter: the caller passes the live counter tensor
+            host.copy_(counter, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            self._count_probe = (host, ev, last)
+        return est
 
     def last_call_overflowed(self) -> torch.Tensor:
         """Device-side flag (0-dim bool tensor, no host sync) of the last render_train call: the march emitted

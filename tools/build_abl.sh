@@ -4,7 +4,10 @@
 set -e
 cd "$(dirname "$0")/.."
 name=$1; shift
-objs=$(ls nerfstyle_amd/csrc/_obj/*.o | grep -v field_bwd.o)
-/opt/rocm/bin/hipcc -O3 -fPIC -std=c++17 --offload-arch=gfx950 -Wno-unused-function "$@" -c nerfstyle_amd/csrc/field_bwd.hip -o tools/abl/field_bwd_$name.o
-/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o tools/abl/libnsr_$name.so $objs tools/abl/field_bwd_$name.o
+objs=$(ls nerfstyle_amd/csrc/_obj/*.o | grep -v "field_bwd.o\|table_scatter.o")
+for f in field_bwd table_scatter; do
+  /opt/rocm/bin/hipcc -O3 -fPIC -std=c++17 --offload-arch=gfx950 -Wno-unused-function "$@" -c nerfstyle_amd/csrc/$f.hip -o tools/abl/${f}_$name.o &
+done
+wait
+/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o tools/abl/libnsr_$name.so $objs tools/abl/field_bwd_$name.o tools/abl/table_scatter_$name.o
 echo tools/abl/libnsr_$name.so

@@ -46,7 +46,7 @@ def main(root, tag, samples_per_launch):
         'kernels': {},
     }
     for k in sorted(set(fetch) | set(write)):
-        short = next((n for n in ('k_field_bwd', 'k_field_fwd', 'k_composite_train_fwd', 'k_composite_train_bwd',
+        short = next((n for n in ('k_field_bwd', 'k_field_fwd', 'k_table_scatter', 'k_order_keys', 'k_composite_train_fwd', 'k_composite_train_bwd',
                                   'k_march_count', 'k_march_emit', 'k_adam') if n in k), None)
         if not short:
             continue
