@@ -20,6 +20,10 @@
 #include "field_common.h"
 #include "table_scatter.h"
 
+#ifndef NSR_BWD_PKMAX
+#define NSR_BWD_PKMAX false
+#endif
+
 // ---- backward LDS image (units: shorts) ------------------------------------------------------
 constexpr int BW_R3T = 0;        // r3^T  [64 x 16]  4 frag16
 constexpr int BW_R2T = 1024;     // r2^T  [64 x 64]  8 frag32
@@ -516,19 +520,19 @@ k_field_bwd(FieldBwdArgs b) {
         f4v logit[1], c1[1], rgb[1];
         mm_layer32<CD, 4, 1>(wl + FW_D1, lane, xd, h);
         if (GOUT) gout_store();            // the previous tile's encoder gradients: after this tile's inputs have been waited for
-        mm_pack64<CD, true>(h, hd);
+        mm_pack64<CD, true, NSR_BWD_PKMAX>(h, hd);
         mm_layer32<CD, 1, 2>(wl + FW_D2, lane, hd, logit);
         mm_layer32<CD, 4, 1>(wl + FW_K1, lane, xc, h);
-        mm_pack64<CD, true>(h, hk);
+        mm_pack64<CD, true, NSR_BWD_PKMAX>(h, hk);
         mm_layer32<CD, 4, 1>(wl + FW_C1A, lane, xc, h);
-        mm_pack64<CD, true>(h, hc);
+        mm_pack64<CD, true, NSR_BWD_PKMAX>(h, hc);
         mm_layer32<CD, 1, 2>(wl + FW_C1B, lane, hc, c1);
         const s4v c1b = mm_round4<CD, false>(c1[0]);
         mm_layer16<CD, 4>(wl + FW_R1, lane, c1b, h);
-        mm_pack64<CD, true>(h, hr1);
+        mm_pack64<CD, true, NSR_BWD_PKMAX>(h, hr1);
         SCQ_PACE(4);
         mm_layer32<CD, 4, 2>(wl + FW_R2, lane, hr1, h);
-        mm_pack64<CD, true>(h, hr2);
+        mm_pack64<CD, true, NSR_BWD_PKMAX>(h, hr2);
         SCQ_PACE(4);
         mm_layer32<CD, 1, 2>(wl + FW_R3, lane, hr2, rgb);
 
