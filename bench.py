@@ -313,7 +313,7 @@ def run_recon(args, dev, rank, world):
     bytes_per_sample = {'field_fwd': 512 * tb, 'field_bwd': 2 * 512 * tb}
     pm = profile_traffic(args)
 
-    sorted_bwd = r.sort_samples is True or (r.sort_samples == 'auto' and n_rays >= r.sort_min_rays)
+    sorted_bwd = r._use_spatial_order(n_rays, False)
     kernel_names = {'field_fwd': ['k_field_fwd'],
                     'field_bwd': ['k_field_bwd', 'k_table_scatter'] if sorted_bwd else ['k_field_bwd']}
 
@@ -386,7 +386,7 @@ def run_recon(args, dev, rank, world):
                           'synthetic bitfield (random-init model has no scene)'.format(rcfg.update_iter, r.cascade * rcfg.grid_size ** 3)
                           if not args.no_occ_update else 'fixed synthetic bitfield, no update'),
             'table_scatter': ('spatial order (nsr_sample_order + stand-alone lattice scatter kernel)'
-                              if (r.sort_samples is True or (r.sort_samples == 'auto' and n_rays >= r.sort_min_rays)) else 'ray order (run tracker, fused)'),
+                              if r._use_spatial_order(n_rays, False) else 'ray order (run tracker, fused)'),
             'sample_capacity_overflows': int(overflow.item()), 'final_loss': float(loss.detach()) / loss_scale * world,
         },
         'kernel_ms_per_step': {k: round(v[1] / args.steps, 4) for k, v in sorted(prof.items())},

@@ -90,7 +90,10 @@ __device__ __forceinline__ void nsr_grid_locate(float x, uint32_t resolution, in
                                                 uint32_t &cell) {
 #pragma clang fp contract(off)
     const float scale = (float)(resolution - (align_corners ? 0u : 1u));
-    float p = x * scale + (align_corners ? 0.0f : 0.5f);
+    // (no "+ 0.0f" for align_corners: with contraction off the compiler must keep that add -- x + 0.0 is not x for -0.0 --
+    // and the value is the same up to the sign of a zero, which no later product or floor can see)
+    float p = x * scale;
+    if (!align_corners) p += 0.5f;
     const float c = fminf(floorf(p), (float)(resolution - 1u));
     cell = (uint32_t)c;
     frac = p - c;

@@ -44,7 +44,8 @@ class Renderer(torch.nn.Module):
         # dense batches only -- on a full 1008x756 frame the backward drops from 49 to 29 ms (+ 1.8 ms sort); on sparse random
         # batches the blocks hold too few samples (65 536 random rays: 6.2 vs 4.5 ms).  True / False force it.
         self.sort_samples = 'auto'
-        self.sort_min_rays = 200000
+        self.sort_min_rays = 200000      # any batch of at least this many rays ...
+        self.sort_min_dense_rays = 16384  # ... or a DENSE pixel set (full frame / patch / crop: neighbouring pixels) of this many
         self.sort_prefix_hint = None     # estimate of the emitted sample count (host int) so a capacity buffer is not sorted whole;
         self._count_probe = None         # None = maintained here from the previous calls' counts, read back without blocking
         self._pinned_bitfield = None
@@ -217,7 +218,7 @@ class Renderer(torch.nn.Module):
             rays.origins, rays.dirs, self.bound, self.march_bitfield, self.cascade, self.cfg.grid_size, nears, fars,
             M, counter, 0., self.cfg.max_steps)
         perm = None
-        if torch.is_grad_enabled() and (self.sort_samples is True or (self.sort_samples == 'auto' and N >= self.sort_min_rays)):
+        if torch.is_grad_enabled() and self._use_spatial_order(N, bool(kwargs.get('dense', False))):
             perm = self.model.sample_order(xyzs, counter, self._sort_prefix(M, counter))
         sigmas, rgbs = self.model.field(xyzs, sigma_only=False, m_dev=counter, density_scale=self.cfg.density_scale, perm=perm)
         weights_sum, depth, image = _composite_train_nosync(sigmas, rgbs, deltas, rays_info, self.cfg.t_thresh)
@@ -226,6 +227,11 @@ class Renderer(torch.nn.Module):
         image = image + (1 - weights_sum).unsqueeze(-1)
         depth = torch.clamp(depth - nears, min=0) / (fars - nears)
         return image, depth, classes
+
+    def _use_spatial_order(self, n_rays: int, dense: bool) -> bool:
+        if self.sort_samples != 'auto':
+            return bool(self.sort_samples)
+        return n_rays >= self.sort_min_rays or (dense and n_rays >= self.sort_min_dense_rays)
 
     def _sort_prefix(self, M: int, counter: torch.Tensor) -> int:
         """How many leading slots of the capacity-sized sample buffer take part in the sort: an estimate of the emitted count
@@ -343,7 +349,9 @@ class Renderer(torch.nn.Module):
                                                camera_flip=self.cfg.flip_camera, pix_subset=pix_subset,
                                                device=self.device)
         render_fn = self.render_train if training else self.render_test
-        output['rgb_map'], output['trans_map'], output['classes'] = render_fn(rays)
+        # a full frame, a patch or a centre crop is a dense pixel set: neighbouring rays share hash-table rows
+        dense = pix_subset is None and num_rays is None
+        output['rgb_map'], output['trans_map'], output['classes'] = render_fn(rays, dense=dense)
         return output
 
 
