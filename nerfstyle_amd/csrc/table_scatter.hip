@@ -128,6 +128,71 @@ __device__ __forceinline__ void lat_flush_dispatch(float4 *__restrict__ lat, int
 }
 
 
+#ifndef NSR_TS_LAZY_LEVELS
+#define NSR_TS_LAZY_LEVELS 16          /* levels below this keep their lattice across blocks; 16 = all lazy (no block flush) */
+#endif
+constexpr int LAT_LAZY_LEVELS = NSR_TS_LAZY_LEVELS;
+
+// Flushes the lattices of levels >= LAT_LAZY_LEVELS, all anchored at block `key`, in ONE pass over their slots
+// [first, end): no per-level dispatch, the reads of four 64-slot trips are in flight together, the anchor of a slot's
+// level is recomputed from the block key (the same nsr_grid_locate the accumulating lanes used).
+__device__ __forceinline__ void lat_flush_block(float4 *__restrict__ lat, const uint32_t *__restrict__ slot_info, uint32_t key,
+                                                uint32_t first, uint32_t end, const NsrLevel *__restrict__ lds_lv,
+                                                float *__restrict__ gt, int lane, bool td, bool tc) {
+    const float rk = 1.0f / (float)(1 << LAT_KEY_BITS);
+    const float o0 = (float)(key & ((1u << LAT_KEY_BITS) - 1u)) * rk, o1 = (float)((key >> LAT_KEY_BITS) & ((1u << LAT_KEY_BITS) - 1u)) * rk,
+                o2 = (float)(key >> (2 * LAT_KEY_BITS)) * rk;
+    uint32_t *rows = reinterpret_cast<uint32_t *>(lat) - 64;
+    const float *lf = reinterpret_cast<const float *>(lat);
+    const int t = lane >> 2, i = lane & 3;
+    const bool on = (i < 2) ? td : tc;
+#pragma unroll 1
+    for (uint32_t c0 = first; c0 < end; c0 += 256) {
+        float4 v[4];
+        uint32_t info[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint32_t k = c0 + 64 * j + (uint32_t)lane;
+            v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            info[j] = 0u;
+            if (k < end) { v[j] = lat[k]; info[j] = slot_info[k]; }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint32_t k0 = c0 + 64 * j, k = k0 + (uint32_t)lane;
+            if (k0 >= end) break;                                              // wave-uniform
+            const bool nz = seq_nonzero(v[j]);
+            const unsigned long long m = __ballot(nz);
+            if (m == 0ull) continue;                                           // wave-uniform: nothing touched in these slots
+            if (nz) {
+                const NsrLevel lv = lds_lv[info[j] & 15u];
+                float ff;
+                uint32_t a0, a1, a2;
+                nsr_grid_locate(o0, lv.resolution, 1, ff, a0);
+                nsr_grid_locate(o1, lv.resolution, 1, ff, a1);
+                nsr_grid_locate(o2, lv.resolution, 1, ff, a2);
+                rows[lane] = lv.offset + nsr_grid_row(lv, a0 + ((info[j] >> 4) & 15u), a1 + ((info[j] >> 8) & 15u), a2 + ((info[j] >> 12) & 15u), 0u);
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                if (((m >> (16 * q)) & 0xFFFFull) == 0ull) continue;          // wave-uniform
+                if ((m >> (16 * q + t)) & 1ull) {
+                    const float val = lf[(k0 + 16 * q + t) * 4 + i];
+                    const uint32_t row = rows[16 * q + t];
+#ifndef NSR_ABL_NO_ATOMIC
+                    if (on) atomicAdd(gt + (size_t)row * 4 + i, val);
+#else
+                    if (on && row == 0xFFFFFFFFu) gt[i] = val;
+#endif
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (nz) lat[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+}
+
 struct TableScatterArgs {
     const float *xyzs;
     const uint32_t *perm;
@@ -156,7 +221,19 @@ k_table_scatter(TableScatterArgs a) {
     NsrLevel *lds_lv = reinterpret_cast<NsrLevel *>(smem);
     if (threadIdx.x < 16) lds_lv[threadIdx.x] = a.lv[threadIdx.x];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    char *base = smem + 16 * sizeof(NsrLevel) + (size_t)wave * (256 + (size_t)a.lat_slots * 16);
+    uint32_t *const slot_info = reinterpret_cast<uint32_t *>(smem + 16 * sizeof(NsrLevel));
+    const size_t slot_bytes = LAT_LAZY_LEVELS < 16 ? (size_t)a.lat_slots * 4 : 0;
+    if (LAT_LAZY_LEVELS < 16) {
+        // slot -> level | x << 4 | y << 8 | z << 12 (corner offset inside the level's lattice)
+        for (int l2 = 0; l2 < 16; l2++) {
+            const uint32_t S2 = a.lv[l2].pad_ & 0xFFu, base2 = a.lv[l2].pad_ >> 8, n2 = S2 * S2 * S2;
+            for (uint32_t k = threadIdx.x; k < n2; k += TS_THREADS) {
+                const uint32_t z = k / (S2 * S2), r = k - z * S2 * S2, y = r / S2, x = r - y * S2;
+                slot_info[base2 + k] = (uint32_t)l2 | (x << 4) | (y << 8) | (z << 12);
+            }
+        }
+    }
+    char *base = smem + 16 * sizeof(NsrLevel) + slot_bytes + (size_t)wave * (256 + (size_t)a.lat_slots * 16);
     float4 *lat = reinterpret_cast<float4 *>(base + 256);               // the 64-entry row scratch sits in front of it
     for (uint32_t k = lane; k < a.lat_slots; k += 64) lat[k] = make_float4(0.f, 0.f, 0.f, 0.f);
     __syncthreads();
@@ -179,6 +256,8 @@ k_table_scatter(TableScatterArgs a) {
     LatState st;
     st.b0 = st.b1 = st.b2 = LAT_NONE;
     uint32_t cur_key = LAT_NONE;
+    const uint32_t flush_first = LAT_LAZY_LEVELS < 16 ? (lds_lv[LAT_LAZY_LEVELS < 16 ? LAT_LAZY_LEVELS : 15].pad_ >> 8) : 0u;
+    const uint32_t flush_end = (lds_lv[15].pad_ >> 8) + (lds_lv[15].pad_ & 0xFFu) * (lds_lv[15].pad_ & 0xFFu) * (lds_lv[15].pad_ & 0xFFu);
 
     // position 16 * tile + s of the order -> buffer index; lanes past the count read the last valid entry (masked later)
     auto fetch_idx = [&](uint32_t tile) -> uint32_t { return a.perm[min(tile * 16 + (uint32_t)s, Mc - 1u)]; };
@@ -213,6 +292,8 @@ k_table_scatter(TableScatterArgs a) {
             const uint32_t key = (uint32_t)__builtin_amdgcn_readlane((int)bkey, step);
             if (key != cur_key) {
                 // ---- the walk enters another block: re-anchor every level at the cell of the block's origin ----
+                if (LAT_LAZY_LEVELS < 16 && cur_key != LAT_NONE)
+                    lat_flush_block(lat, slot_info, cur_key, flush_first, flush_end, lds_lv, gt, lane, td, tc);
                 cur_key = key;
                 const float o0 = (float)(key & ((1u << LAT_KEY_BITS) - 1u)) * rk, o1 = (float)((key >> LAT_KEY_BITS) & ((1u << LAT_KEY_BITS) - 1u)) * rk,
                             o2 = (float)(key >> (2 * LAT_KEY_BITS)) * rk;
@@ -222,7 +303,7 @@ k_table_scatter(TableScatterArgs a) {
                 nsr_grid_locate(o1, lv.resolution, 1, ff, n1);
                 nsr_grid_locate(o2, lv.resolution, 1, ff, n2);
                 const bool chg = (n0 != st.b0) | (n1 != st.b1) | (n2 != st.b2);
-                unsigned long long mm = __ballot(chg);
+                unsigned long long mm = __ballot(chg && l < LAT_LAZY_LEVELS);
                 while (mm) {
                     const int fl = (int)(__builtin_ctzll(mm) >> 2);
                     mm &= ~(0xFull << (fl * 4));
@@ -275,8 +356,9 @@ k_table_scatter(TableScatterArgs a) {
     }
     // every level's lattice leaves
     __builtin_amdgcn_wave_barrier();
+    if (LAT_LAZY_LEVELS < 16 && cur_key != LAT_NONE) lat_flush_block(lat, slot_info, cur_key, flush_first, flush_end, lds_lv, gt, lane, td, tc);
 #pragma unroll 1
-    for (int fl = 0; fl < 16; fl++) lat_flush_dispatch(lat, fl, st, lds_lv, gt, lane, td, tc);
+    for (int fl = 0; fl < LAT_LAZY_LEVELS; fl++) lat_flush_dispatch(lat, fl, st, lds_lv, gt, lane, td, tc);
 }
 
 bool nsr_table_scatter_supported(const NsrLevel *lv) {
@@ -299,7 +381,7 @@ int nsr_table_scatter_launch(const NsrLevel *levels, const float *bmin, const fl
     a.xyzs = xyzs; a.perm = perm; a.m_dev = m_dev; a.M = M; a.gin = (const float4 *)gin; a.grad_tables = grad_tables;
     for (int i = 0; i < 3; i++) { a.bmin[i] = bmin[i]; a.bsize[i] = bsize[i]; }
     a.td = td; a.tc = tc;
-    const size_t lds = 16 * sizeof(NsrLevel) + (TS_THREADS / 64) * ts_wave_bytes(a.lat_slots);
+    const size_t lds = 16 * sizeof(NsrLevel) + (LAT_LAZY_LEVELS < 16 ? (size_t)a.lat_slots * 4 : 0) + (TS_THREADS / 64) * ts_wave_bytes(a.lat_slots);
     static bool attr_set[64] = {};
     int dev = 0;
     (void)hipGetDevice(&dev);
