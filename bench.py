@@ -289,8 +289,13 @@ def run_recon(args, dev, rank, world):
     t0 = time.perf_counter()
     if graph_ev:
         graph_ev[0].record()
+    _tr = []
     for it in range(args.steps):
         loss = step(args.warmup + it)
+        if os.environ.get('NSR_BENCH_TRACE'):
+            torch.cuda.synchronize(); _tr.append(time.perf_counter())
+    if _tr:
+        print('[trace] per-step ms:', [round((b - a) * 1e3, 1) for a, b in zip([t0] + _tr[:-1], _tr)], file=sys.stderr)
     if graph_ev:
         graph_ev[1].record()
     torch.cuda.synchronize()

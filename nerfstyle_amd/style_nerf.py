@@ -121,8 +121,14 @@ class _field(Function):
         tables = model._gather_tables()
         ws = None
         if ctx.perm is not None:
-            # [M][16] float4 of per-level encoder gradients for the spatially ordered table scatter (second kernel)
-            ws = torch.empty(int(L.lib().nsr_field_backward_workspace_bytes(M, 1)) // 4, dtype=torch.float32, device=dev)
+            # [M][16] float4 of per-level encoder gradients for the spatially ordered table scatter (second kernel): 256 B
+            # per sample SLOT (31 GB for a 122 M-slot capacity buffer), kept on the model and only ever grown -- the
+            # caching allocator would otherwise be asked for the largest block of the step every step
+            need = int(L.lib().nsr_field_backward_workspace_bytes(M, 1)) // 4
+            ws = getattr(model, '_bwd_ws', None)
+            if ws is None or ws.device != dev or ws.numel() < need:
+                model._bwd_ws = None
+                ws = model._bwd_ws = torch.empty(need, dtype=torch.float32, device=dev)
         with profiling.timed('field_bwd'):
             L.check(L.lib().nsr_field_backward(
                 ctypes.byref(desc), L.p(tables), L.p(model._mlp_flat()), L.p(xyzs), M, L.p(ctx.m_dev),
