@@ -13,7 +13,12 @@ CSRC = os.path.join(HERE, 'csrc')
 OBJ = os.path.join(HERE, 'csrc', '_obj')
 LIB = os.path.join(HERE, 'libnsr_hip.so')
 ARCH = 'gfx950'
-SOURCES = ['raymarch.hip', 'occupancy.hip', 'sample_order.hip', 'gridenc.hip', 'field.hip', 'field_bwd.hip', 'table_scatter.hip', 'mlp.hip', 'optim.hip']
+SOURCES = ['raymarch.hip', 'occupancy.hip', 'sample_order.hip', 'gridenc.hip', 'field.hip', 'field_bwd.hip', 'field_bwd_gout.hip', 'table_scatter.hip', 'mlp.hip',
+           'optim.hip']
+# MFMA destinations in VGPRs (no AGPR round trip for results that VALU code consumes next): the forward, and the GOUT backward,
+# whose 240 weight-gradient accumulators are pinned to AGPRs by inline assembly instead (field_bwd.hip)
+EXTRA_FLAGS = {'field.hip': ['-mllvm', '--amdgpu-mfma-vgpr-form'],
+               'field_bwd_gout.hip': ['-DNSR_BWD_ASM_WGRAD=1', '-mllvm', '--amdgpu-mfma-vgpr-form']}
 HEADERS = ['nsr_common.h', 'rm_util.h', 'table_scatter.h', 'mfma_tiles.h', 'field_common.h', os.path.join('..', '..', 'include', 'nsr.h')]
 FLAGS = ['-O3', '-fPIC', '-std=c++17', '--offload-arch=' + ARCH, '-Wall', '-Wno-unused-function']
 
@@ -41,8 +46,8 @@ def build(force=False, verbose=False):
     for s in srcs:
         src = os.path.join(CSRC, s)
         obj = os.path.join(OBJ, s.replace('.hip', '.o'))
-        if force or _stale(obj, [src] + hdrs):
-            jobs.append([hipcc] + FLAGS + ['-c', src, '-o', obj])
+        if force or _stale(obj, [src] + hdrs + ([os.path.join(CSRC, 'field_bwd.hip')] if s == 'field_bwd_gout.hip' else [])):
+            jobs.append([hipcc] + FLAGS + EXTRA_FLAGS.get(s, []) + ['-c', src, '-o', obj])
 
     def run(cmd):
         if verbose:

@@ -23,6 +23,12 @@
 #ifndef NSR_BWD_PKMAX
 #define NSR_BWD_PKMAX false
 #endif
+#ifndef NSR_BWD_NET_ORDER
+#define NSR_BWD_NET_ORDER 0
+#endif
+#ifndef NSR_BWD_ASM_WGRAD
+#define NSR_BWD_ASM_WGRAD 0
+#endif
 
 // ---- backward LDS image (units: shorts) ------------------------------------------------------
 constexpr int BW_R3T = 0;        // r3^T  [64 x 16]  4 frag16
@@ -71,12 +77,27 @@ __device__ __forceinline__ void field_build_bw(short *lds, const float *__restri
 //   dW[o][i] += sum_s G[o][s] * A[i][s]
 // Gt / At are the transposed blocks (lane = feature, elements = samples 4g+e).  Tile (ot,it) of
 // the result: lane (i = lane&15, g) element e = dW[16ot + 4g + e][16it + i].
+// The 60 accumulator tiles are pinned to the ACCUMULATOR half of the register file by inline assembly ("+a"), and this file
+// is compiled with -mllvm --amdgpu-mfma-vgpr-form: every other MFMA (forward recompute, dgrad, the identity transposes) then
+// writes straight to VGPRs.  Left to its heuristics the compiler gives ALL MFMAs of a kernel that needs AGPRs an AGPR
+// destination and copies each transient result back (396 v_accvgpr_read per 16-sample tile, 22 % of the loop).
+// The s_nop covers the VALU-write -> MFMA-read distance the hazard recogniser cannot see through the asm; the operands
+// always come from a VALU rounding step (mm_round4), never directly from another MFMA.
+template <int CD>
+__device__ __forceinline__ void field_wgrad_mfma(f4v &acc, s4v a, s4v b) {
+#if NSR_BWD_ASM_WGRAD
+    if (CD == NSR_F16) asm("s_nop 1\n\tv_mfma_f32_16x16x16_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+    else asm("s_nop 1\n\tv_mfma_f32_16x16x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+#else
+    acc = MM<CD>::k16(a, b, acc);
+#endif
+}
 template <int CD, int NG, int NA>
 __device__ __forceinline__ void field_wgrad(f4v (&acc)[NG * NA], const s4v (&Gt)[NG], const s4v (&At)[NA]) {
 #pragma unroll
     for (int ot = 0; ot < NG; ot++) {
 #pragma unroll
-        for (int it = 0; it < NA; it++) acc[ot * NA + it] = MM<CD>::k16(Gt[ot], At[it], acc[ot * NA + it]);
+        for (int it = 0; it < NA; it++) field_wgrad_mfma<CD>(acc[ot * NA + it], Gt[ot], At[it]);
     }
 }
 
@@ -513,6 +534,139 @@ k_field_bwd(FieldBwdArgs b) {
 
         // paced drain of the previous tile's records: SCQ_PACE(n) issues <= n atomic wave-instructions
 #define SCQ_PACE(n) do { if (!GOUT) scq_pace(q, gt1, lane, td, tc, (n), false); } while (0)
+#if NSR_BWD_NET_ORDER
+        // ================= one net at a time: forward recompute -> dgrad -> wgrad, then its activations are dead ===========
+        // (The straight order -- all four forwards, then all backwards -- keeps hd, hk, hc, hr1, hr2 alive together: 40
+        // registers that the accumulator-heavy kernel does not have; the compiler then parks MFMA results in AGPRs and
+        // copies them back, ~400 v_accvgpr_read per tile.)
+        s8v xd[1] = {cur.xd}, xc[1] = {cur.xc};
+        f4v h[4];
+        s4v xct[2], xdt[2];
+        // ---- density: 32 -> 64 -> 1 --------------------------------------------------------------------------------
+        f4v gxd[2];
+        {
+            s8v hd[2];
+            f4v logit[1];
+            mm_layer32<CD, 4, 1>(wl + FW_D1, lane, xd, h);
+            if (GOUT) gout_store();        // the previous tile's encoder gradients: after this tile's inputs have been waited for
+            mm_pack64<CD, true, NSR_BWD_PKMAX>(h, hd);
+            mm_layer32<CD, 1, 2>(wl + FW_D2, lane, hd, logit);
+            s4v dyd;
+            {
+                // sigma = exp(logit) * density_scale; trunc_exp backward clamps (tcnn_nerf.py:62-66)
+                float gd = 0.f;
+                if (valid && g == 0) gd = cur_gsig * a.density_scale * expf(fminf(fmaxf(logit[0][0], -15.0f), 15.0f));
+                dyd[0] = MM<CD>::cvt(gd); dyd[1] = MM<CD>::cvt(0.f); dyd[2] = dyd[1]; dyd[3] = dyd[1];
+            }
+            s8v gh[2];
+            s4v ght[4], hdt[4];
+            mm_layer16<CD, 4>(wt + BW_D2T, lane, dyd, h);
+            field_mask_pack<CD>(h, hd, gh);
+            mm_layer32<CD, 2, 2>(wt + BW_D1T, lane, gh, gxd);
+            SCQ_PACE(4);
+            field_tr4<CD>(hd, ident, hdt);
+            const s4v dydt[1] = {mm_transpose16<CD>(dyd, ident)};
+            field_wgrad<CD, 1, 4>(w_d2, dydt, hdt);
+            SCQ_PACE(4);
+            field_tr2<CD>(xd, ident, xdt);
+            field_tr4<CD>(gh, ident, ght);
+            field_wgrad<CD, 4, 2>(w_d1, ght, xdt);
+            SCQ_PACE(4);
+        }
+        field_tr2<CD>(xc, ident, xct);
+        // ---- class: 32 -> 64 -> nc (rows 3..) ------------------------------------------------------------------------
+        f4v gxc[2];
+        {
+            s8v hk[2];
+            mm_layer32<CD, 4, 1>(wl + FW_K1, lane, xc, h);
+            mm_pack64<CD, true, NSR_BWD_PKMAX>(h, hk);
+            s4v dyk;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const int ch = 4 * g + e;
+                dyk[e] = MM<CD>::cvt((valid && ch >= 3 && (uint32_t)ch < a.C_ch) ? cur_grgb[e] : 0.f);
+            }
+            s8v gh[2];
+            s4v ght[4], hkt[4];
+            mm_layer16<CD, 4>(wt + BW_K2T, lane, dyk, h);
+            field_mask_pack<CD>(h, hk, gh);
+            mm_layer32<CD, 2, 2>(wt + BW_K1T, lane, gh, gxc);
+            SCQ_PACE(4);
+            field_tr4<CD>(hk, ident, hkt);
+            const s4v dykt[1] = {mm_transpose16<CD>(dyk, ident)};
+            field_wgrad<CD, 1, 4>(w_k2, dykt, hkt);
+            SCQ_PACE(4);
+            field_tr4<CD>(gh, ident, ght);
+            field_wgrad<CD, 4, 2>(w_k1, ght, xct);
+            SCQ_PACE(4);
+        }
+        // ---- colour: 32 -> 64 -> 16 -> 64 -> 64 -> 3 (sigmoid) -------------------------------------------------------
+        {
+            s8v hc[2], hr1[2], hr2[2];
+            f4v c1[1], rgb[1];
+            mm_layer32<CD, 4, 1>(wl + FW_C1A, lane, xc, h);
+            mm_pack64<CD, true, NSR_BWD_PKMAX>(h, hc);
+            mm_layer32<CD, 1, 2>(wl + FW_C1B, lane, hc, c1);
+            const s4v c1b = mm_round4<CD, false>(c1[0]);
+            mm_layer16<CD, 4>(wl + FW_R1, lane, c1b, h);
+            mm_pack64<CD, true, NSR_BWD_PKMAX>(h, hr1);
+            mm_layer32<CD, 4, 2>(wl + FW_R2, lane, hr1, h);
+            mm_pack64<CD, true, NSR_BWD_PKMAX>(h, hr2);
+            SCQ_PACE(4);
+            mm_layer32<CD, 1, 2>(wl + FW_R3, lane, hr2, rgb);
+            s4v dyr;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const int ch = 4 * g + e;
+                float gr = 0.f;
+                if (valid && ch < 3) {
+                    const float sg = field_sigmoid(rgb[0][e]);
+                    gr = cur_grgb[e] * sg * (1.0f - sg);
+                }
+                dyr[e] = MM<CD>::cvt(gr);
+            }
+            s8v g2[2], g1[2];
+            s4v gc1;
+            mm_layer16<CD, 4>(wt + BW_R3T, lane, dyr, h);
+            field_mask_pack<CD>(h, hr2, g2);
+            mm_layer32<CD, 4, 2>(wt + BW_R2T, lane, g2, h);
+            field_mask_pack<CD>(h, hr1, g1);
+            f4v t1[1];
+            mm_layer32<CD, 1, 2>(wt + BW_R1T, lane, g1, t1);
+            gc1 = mm_round4<CD, false>(t1[0]);
+            {
+                s4v hr2t[4], g2t[4];
+                field_tr4<CD>(hr2, ident, hr2t);
+                const s4v dyrt[1] = {mm_transpose16<CD>(dyr, ident)};
+                field_wgrad<CD, 1, 4>(w_r3, dyrt, hr2t);
+                SCQ_PACE(4);
+                s4v hr1t[4];
+                field_tr4<CD>(g2, ident, g2t);
+                field_tr4<CD>(hr1, ident, hr1t);
+                field_wgrad<CD, 4, 4>(w_r2, g2t, hr1t);
+                SCQ_PACE(4);
+            }
+            {
+                s4v g1t[4];
+                field_tr4<CD>(g1, ident, g1t);
+                const s4v c1t[1] = {mm_transpose16<CD>(c1b, ident)};
+                field_wgrad<CD, 4, 1>(w_r1, g1t, c1t);
+                SCQ_PACE(4);
+            }
+            s8v gh[2];
+            s4v ght[4], hct[4];
+            mm_layer16<CD, 4>(wt + BW_C1BT, lane, gc1, h);
+            field_mask_pack<CD>(h, hc, gh);
+            mm_layer32_acc<CD, 2, 2>(wt + BW_C1AT, lane, gh, gxc);
+            field_tr4<CD>(hc, ident, hct);
+            const s4v gc1t[1] = {mm_transpose16<CD>(gc1, ident)};
+            field_wgrad<CD, 1, 4>(w_c1b, gc1t, hct);
+            SCQ_PACE(4);
+            field_tr4<CD>(gh, ident, ght);
+            field_wgrad<CD, 4, 2>(w_c1a, ght, xct);
+            SCQ_PACE(4);
+        }
+#else
         // ================= recompute forward, keeping rounded activations ====================
         s8v xd[1] = {cur.xd}, xc[1] = {cur.xc};
         f4v h[4];
@@ -642,6 +796,8 @@ k_field_bwd(FieldBwdArgs b) {
             SCQ_PACE(4);
         }
 
+#endif
+
         // ================= table scatter =======================================================
         // gxd[t][2*(i&1)+f] is d L / d feature f of level lvl[i] (t = i >> 1): same lane<->level map
         // as the forward encode.  The scatter is VALU + LDS only: its records go to the ring and leave as
@@ -705,6 +861,61 @@ k_field_bwd(FieldBwdArgs b) {
     }
 }
 
+// ---- launch of one instantiation (LDS attribute set once per process and instantiation: idempotent, so a race is harmless;
+// keeps the call free of non-stream API calls, e.g. while the caller captures a hipGraph) ----
+#ifdef NSR_ABL_STATS
+#define NSR_ABL_REPORT(M)                                                                                          \
+    do {                                                                                                          \
+        unsigned long long h[8], z[8] = {0};                                                                      \
+        hipDeviceSynchronize();                                                                                   \
+        hipMemcpyFromSymbol(h, HIP_SYMBOL(g_stats), sizeof(h));                                                   \
+        hipMemcpyToSymbol(HIP_SYMBOL(g_stats), z, sizeof(z));                                                     \
+        fprintf(stderr, "[abl] M=%u records=%llu hits=%llu drain_instr=%llu forced=%llu clk wait=%llu mlp=%llu scatter=%llu loads=%llu\n", (M), h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]); \
+    } while (0)
+#else
+#define NSR_ABL_REPORT(M) do { } while (0)
+#endif
+template <typename TT, int CD, bool FEATS, bool GOUT>
+static int field_bwd_launch_one(const FieldBwdArgs &b, dim3 grid, hipStream_t s) {
+    static bool lds_attr_set[64] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (!lds_attr_set[dev & 63]) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_field_bwd<TT, CD, FEATS, GOUT>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)BWD_LDS_BYTES) != hipSuccess)
+            return NSR_ERR_LAUNCH;
+        lds_attr_set[dev & 63] = true;
+    }
+    hipLaunchKernelGGL((k_field_bwd<TT, CD, FEATS, GOUT>), grid, dim3(BWD_THREADS), BWD_LDS_BYTES, s, b);
+    NSR_ABL_REPORT(b.f.M);
+    return nsr_launch_status();
+}
+template <bool GOUT>
+static int field_bwd_launch_variant(const FieldBwdArgs &b, int table_dtype, int compute_dtype, bool feats, dim3 grid, hipStream_t s) {
+    if (feats) {                                 // no gather in the kernel: the table type does not matter
+        if (compute_dtype == NSR_F16) return field_bwd_launch_one<float, NSR_F16, true, GOUT>(b, grid, s);
+        if (compute_dtype == NSR_BF16) return field_bwd_launch_one<float, NSR_BF16, true, GOUT>(b, grid, s);
+    } else {
+        if (table_dtype == NSR_F32 && compute_dtype == NSR_F16) return field_bwd_launch_one<float, NSR_F16, false, GOUT>(b, grid, s);
+        if (table_dtype == NSR_F32 && compute_dtype == NSR_BF16) return field_bwd_launch_one<float, NSR_BF16, false, GOUT>(b, grid, s);
+        if (table_dtype == NSR_F16 && compute_dtype == NSR_F16) return field_bwd_launch_one<_Float16, NSR_F16, false, GOUT>(b, grid, s);
+        if (table_dtype == NSR_F16 && compute_dtype == NSR_BF16) return field_bwd_launch_one<_Float16, NSR_BF16, false, GOUT>(b, grid, s);
+    }
+    return NSR_ERR_UNSUPPORTED;
+}
+
+// The GOUT instantiations live in their own translation unit (field_bwd_gout.hip includes this file with
+// NSR_BWD_TU_GOUT): they are compiled with the accumulators pinned to AGPRs by inline assembly and every other MFMA in
+// VGPR form (-DNSR_BWD_ASM_WGRAD=1 -mllvm --amdgpu-mfma-vgpr-form: 1816 -> 1435 instructions per tile, 14.4 -> 13.5 ms);
+// the tracker instantiations keep the compiler's own choice -- the same treatment made them slower (49 -> 52 ms: their
+// paced atomic drains are tuned to the old schedule).
+int nsr_field_bwd_launch_gout(const FieldBwdArgs &b, int table_dtype, int compute_dtype, bool feats, dim3 grid, hipStream_t s);
+
+#ifdef NSR_BWD_TU_GOUT
+int nsr_field_bwd_launch_gout(const FieldBwdArgs &b, int table_dtype, int compute_dtype, bool feats, dim3 grid, hipStream_t s) {
+    return field_bwd_launch_variant<true>(b, table_dtype, compute_dtype, feats, grid, s);
+}
+#else
 extern "C" {
 
 uint64_t nsr_field_backward_workspace_bytes(uint32_t M, int with_perm) {
@@ -744,59 +955,14 @@ int nsr_field_backward(const nsr_field_desc *desc, const void *tables, const flo
     b.grad_sigmas = grad_sigmas; b.grad_rgbs = grad_rgbs; b.grad_tables = grad_tables; b.grad_mlp = grad_mlp;
     b.train_density = train_density_table; b.train_color = train_color_table; b.nc = desc->num_classes;
     hipStream_t s = (hipStream_t)stream;
-    const dim3 grid(nblocks), block(BWD_THREADS);
-#ifdef NSR_ABL_STATS
-#define NSR_ABL_REPORT()                                                                                          \
-    do {                                                                                                          \
-        unsigned long long h[8], z[8] = {0};                                                                      \
-        hipDeviceSynchronize();                                                                                   \
-        hipMemcpyFromSymbol(h, HIP_SYMBOL(g_stats), sizeof(h));                                                   \
-        hipMemcpyToSymbol(HIP_SYMBOL(g_stats), z, sizeof(z));                                                     \
-        fprintf(stderr, "[abl] M=%u records=%llu hits=%llu drain_instr=%llu forced=%llu clk wait=%llu mlp=%llu scatter=%llu loads=%llu\n", M, h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]); \
-    } while (0)
-#else
-#define NSR_ABL_REPORT() do { } while (0)
-#endif
-#define NSR_BWD_LAUNCH_(TT, CD, FEATS, SORTED, LDSB)                                                              \
-    do {                                                                                                       \
-        /* once per process and instantiation (idempotent, so a race is harmless): keeps the call free of   */ \
-        /* non-stream API calls, e.g. while the caller captures a hipGraph                                   */ \
-        static bool lds_attr_set[64] = {};                                                                     \
-        int dev_ = 0;                                                                                          \
-        (void)hipGetDevice(&dev_);                                                                             \
-        if (!lds_attr_set[dev_ & 63]) {                                                                        \
-            if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_field_bwd<TT, CD, FEATS, SORTED>),       \
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDSB)) != hipSuccess)    \
-                return NSR_ERR_LAUNCH;                                                                         \
-            lds_attr_set[dev_ & 63] = true;                                                                    \
-        }                                                                                                      \
-        hipLaunchKernelGGL((k_field_bwd<TT, CD, FEATS, SORTED>), grid, block, (LDSB), s, b);                   \
-        NSR_ABL_REPORT();                                                                                      \
-        if (hipGetLastError() != hipSuccess) return NSR_ERR_LAUNCH;                                            \
-        if (SORTED) {                                                                                          \
-            /* second kernel: the table scatter in the permutation's order, many waves per CU */               \
-            return nsr_table_scatter_launch(b.f.lv, b.f.bmin, b.f.bsize, xyzs, perm, m_dev, M, workspace, grad_tables, \
-                                            train_density_table, train_color_table, s);                        \
-        }                                                                                                      \
-        return NSR_OK;                                                                                         \
-    } while (0)
-#define NSR_BWD_LAUNCH(TT, CD, FEATS)                                                                          \
-    do {                                                                                                       \
-        if (gout) NSR_BWD_LAUNCH_(TT, CD, FEATS, true, BWD_LDS_BYTES);                                         \
-        NSR_BWD_LAUNCH_(TT, CD, FEATS, false, BWD_LDS_BYTES);                                                  \
-    } while (0)
-    if (feats != nullptr) {                      // no gather in the kernel: the table type does not matter
-        if (desc->compute_dtype == NSR_F16) NSR_BWD_LAUNCH(float, NSR_F16, true);
-        if (desc->compute_dtype == NSR_BF16) NSR_BWD_LAUNCH(float, NSR_BF16, true);
-    } else {
-        if (desc->table_dtype == NSR_F32 && desc->compute_dtype == NSR_F16) NSR_BWD_LAUNCH(float, NSR_F16, false);
-        if (desc->table_dtype == NSR_F32 && desc->compute_dtype == NSR_BF16) NSR_BWD_LAUNCH(float, NSR_BF16, false);
-        if (desc->table_dtype == NSR_F16 && desc->compute_dtype == NSR_F16) NSR_BWD_LAUNCH(_Float16, NSR_F16, false);
-        if (desc->table_dtype == NSR_F16 && desc->compute_dtype == NSR_BF16) NSR_BWD_LAUNCH(_Float16, NSR_BF16, false);
-    }
-#undef NSR_BWD_LAUNCH
-#undef NSR_BWD_LAUNCH_
-    return NSR_ERR_UNSUPPORTED;
+    const dim3 grid(nblocks);
+    if (!gout) return field_bwd_launch_variant<false>(b, desc->table_dtype, desc->compute_dtype, feats != nullptr, grid, s);
+    const int st1 = nsr_field_bwd_launch_gout(b, desc->table_dtype, desc->compute_dtype, feats != nullptr, grid, s);
+    if (st1 != NSR_OK) return st1;
+    // second kernel: the table scatter in the permutation's order, many waves per CU
+    return nsr_table_scatter_launch(b.f.lv, b.f.bmin, b.f.bsize, xyzs, perm, m_dev, M, workspace, grad_tables, train_density_table,
+                                    train_color_table, s);
 }
 
 }   // extern "C"
+#endif
