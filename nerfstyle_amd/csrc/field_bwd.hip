@@ -20,11 +20,22 @@
 #include "field_common.h"
 #include "table_scatter.h"
 
+// Schedule knobs, measured on the bench frame (48.6 M samples):
+//   NSR_BWD_PKMAX      ReLU on packed halves (v_pk_max_f16): GOUT kernel 13.5 -> 13.0 ms, tracker kernel 49.0 -> 49.5 ms
+//   NSR_BWD_NET_ORDER  one net at a time (forward recompute -> dgrad -> wgrad per net): tracker 49.0 -> 48.0 ms, GOUT 13.5 -> 13.4 ms
 #ifndef NSR_BWD_PKMAX
+#ifdef NSR_BWD_TU_GOUT
+#define NSR_BWD_PKMAX true
+#else
 #define NSR_BWD_PKMAX false
 #endif
+#endif
 #ifndef NSR_BWD_NET_ORDER
-#define NSR_BWD_NET_ORDER 0
+#ifdef NSR_BWD_TU_GOUT
+#define NSR_BWD_NET_ORDER 0          /* with PKMAX: 13.0 ms in the straight order, 13.45 ms net by net */
+#else
+#define NSR_BWD_NET_ORDER 1
+#endif
 #endif
 #ifndef NSR_BWD_ASM_WGRAD
 #define NSR_BWD_ASM_WGRAD 0
