@@ -229,6 +229,8 @@ class Renderer(torch.nn.Module):
         return image, depth, classes
 
     def _use_spatial_order(self, n_rays: int, dense: bool) -> bool:
+        if getattr(self.model, '_spatial_scatter_unsupported', False):
+            return False                 # learnt from a backward that fell back (style_nerf._field.backward)
         if self.sort_samples != 'auto':
             return bool(self.sort_samples)
         return n_rays >= self.sort_min_rays or (dense and n_rays >= self.sort_min_dense_rays)

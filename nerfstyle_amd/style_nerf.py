@@ -130,11 +130,19 @@ class _field(Function):
                 model._bwd_ws = None
                 ws = model._bwd_ws = torch.empty(need, dtype=torch.float32, device=dev)
         with profiling.timed('field_bwd'):
-            L.check(L.lib().nsr_field_backward(
-                ctypes.byref(desc), L.p(tables), L.p(model._mlp_flat()), L.p(xyzs), M, L.p(ctx.m_dev),
-                L.p(grad_sigmas), L.p(grad_rgbs), L.p(ga), ga.data_ptr() + model.table_elems * 4,
-                int(model.train_density_table), int(model.train_color_table), L.p(ctx.feats), L.p(ctx.perm), L.p(ws),
-                L.stream()), 'field_backward')
+            def call(perm, wsp):
+                return L.lib().nsr_field_backward(
+                    ctypes.byref(desc), L.p(tables), L.p(model._mlp_flat()), L.p(xyzs), M, L.p(ctx.m_dev),
+                    L.p(grad_sigmas), L.p(grad_rgbs), L.p(ga), ga.data_ptr() + model.table_elems * 4,
+                    int(model.train_density_table), int(model.train_color_table), L.p(ctx.feats), L.p(perm), L.p(wsp),
+                    L.stream())
+            st = call(ctx.perm, ws)
+            if st == -2 and ctx.perm is not None:
+                # NSR_ERR_UNSUPPORTED: a grid finer than the spatial scatter's LDS lattices hold (finest resolution above
+                # ~5 cells per 1/1024 block) -- nothing was launched; the fused run-tracker backward takes over
+                model._spatial_scatter_unsupported = True
+                st = call(None, None)
+            L.check(st, 'field_backward')
         return None, None, None, None, None, None, None, None
 
 

@@ -424,3 +424,36 @@ def test_field_other_class_counts(O, dev, nc):
     assert rel_l2(gt[:, 0, :], ref.emb_density.grad.numpy()) < 5e-3
     assert rel_l2(gt[:, 1, :], ref.emb_color.grad.numpy()) < 5e-3
     assert rel_l2(ga[m.table_elems + 12288:m.table_elems + 15360], ref.p_class.grad.numpy()) < 5e-3
+
+
+def test_spatial_scatter_falls_back_on_unsupported_grid(O, dev):
+    """A grid whose finest level has more than ~5 cells per 1/1024 sample-order block does not fit the scatter kernel's LDS
+    lattices: nsr_field_backward reports NSR_ERR_UNSUPPORTED for a `perm` call without launching anything, and the host layer
+    re-issues the fused (run tracker) backward -- same gradient as a call without perm."""
+    import ctypes
+    from nerfstyle_amd import _lib as L
+    from nerfstyle_amd.common import BBox
+    from nerfstyle_amd.config import NetworkConfig, PosEncConfig
+    from nerfstyle_amd.style_nerf import StyleTCNerf
+    # max_res_coeff 4096: finest resolution 16384 -> 16 cells per block
+    m = StyleTCNerf(NetworkConfig(pos_enc=PosEncConfig(max_res_coeff=4096)), BBox.from_radius(2.0), 5, enc_dtype=torch.float32,
+                    use_dir=False).to(dev)
+    with torch.no_grad():
+        m.arena[:m.table_elems].uniform_(-0.5, 0.5)
+        m.arena.add_(0)
+    rng = np.random.default_rng(3)
+    pts = T((rng.random((5000, 3)) * 4 - 2).astype(np.float32), dev)
+    gs = T((rng.standard_normal(5000) * 1e-2).astype(np.float32), dev)
+    gr = T(rng.standard_normal((5000, 8)).astype(np.float32), dev)
+
+    def run(p):
+        m.arena.grad = None
+        m.grad_arena = None
+        sig, rgb = m.field(pts, False, perm=p)
+        torch.autograd.backward([sig, rgb], [gs, gr])
+        return m.arena.grad.detach().clone()
+    g0 = run(None)
+    assert not getattr(m, '_spatial_scatter_unsupported', False)
+    g1 = run(m.sample_order(pts))
+    assert m._spatial_scatter_unsupported
+    assert float(g0.abs().sum()) > 0 and rel_l2(g1.cpu().numpy(), g0.cpu().numpy()) < 2e-5
