@@ -209,6 +209,9 @@ struct TableScatterArgs {
 #ifndef NSR_TS_THREADS
 #define NSR_TS_THREADS 256        /* measured on the bench frame: 64 -> 35.6 ms, 128 -> 30.6, 256 -> 29.4 (A + B) */
 #endif
+#ifndef NSR_TS_LDS_ATOMIC
+#define NSR_TS_LDS_ATOMIC 0
+#endif
 #ifndef NSR_TS_UNROLL
 #define NSR_TS_UNROLL 4         /* 1 -> 31.7 ms, 2 -> 30.6, 4 -> 29.4, 8 -> 29.6 */
 #endif
@@ -344,11 +347,25 @@ k_table_scatter(TableScatterArgs a) {
                 wB = 0.0f;
             }
             float4 *const slot = mylat + ((r2 * S + r1) * S + r0);
+#if NSR_TS_LDS_ATOMIC
+            // fire-and-forget LDS float adds: no read -> fma -> write round trip to wait for (the lattice is private to the wave
+            // and the 64 lanes of a step touch 128 different slots, so nothing conflicts)
+            float *const sf = reinterpret_cast<float *>(slot);
+            __hip_atomic_fetch_add(sf + 0, wA * gr.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            __hip_atomic_fetch_add(sf + 1, wA * gr.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            __hip_atomic_fetch_add(sf + 2, wA * gr.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            __hip_atomic_fetch_add(sf + 3, wA * gr.w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            __hip_atomic_fetch_add(sf + 4, wB * gr.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            __hip_atomic_fetch_add(sf + 5, wB * gr.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            __hip_atomic_fetch_add(sf + 6, wB * gr.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            __hip_atomic_fetch_add(sf + 7, wB * gr.w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+#else
             float4 va = slot[0], vb = slot[1];
             va.x = fmaf(wA, gr.x, va.x); va.y = fmaf(wA, gr.y, va.y); va.z = fmaf(wA, gr.z, va.z); va.w = fmaf(wA, gr.w, va.w);
             vb.x = fmaf(wB, gr.x, vb.x); vb.y = fmaf(wB, gr.y, vb.y); vb.z = fmaf(wB, gr.z, vb.z); vb.w = fmaf(wB, gr.w, vb.w);
             slot[0] = va;
             slot[1] = vb;
+#endif
         }
         x0 = nx0; x1 = nx1; x2 = nx2;
         idx = idx_next;
