@@ -285,7 +285,7 @@ def run_recon(args, dev, rank, world):
         cnt = r._last_counter
         total_samples.add_(cnt[0].to(torch.int64))
         overflow.add_((cnt[0] >= r.sample_capacity(n_rays)).to(torch.int64))
-        return loss
+        return loss.detach()           # not the graph: whatever its nodes still hold would stay allocated over the next step
 
     for it in range(args.warmup):
         step(it)
@@ -306,9 +306,14 @@ def run_recon(args, dev, rank, world):
     for it in range(args.steps):
         loss = step(args.warmup + it)
         if os.environ.get('NSR_BENCH_TRACE'):
-            torch.cuda.synchronize(); _tr.append(time.perf_counter())
+            torch.cuda.synchronize()
+            ms = torch.cuda.memory_stats(dev)
+            _tr.append((time.perf_counter(), ms.get('num_device_alloc', 0), ms.get('num_device_free', 0), ms.get('reserved_bytes.all.current', 0) >> 20))
     if _tr:
-        print('[trace] per-step ms:', [round((b - a) * 1e3, 1) for a, b in zip([t0] + _tr[:-1], _tr)], file=sys.stderr)
+        print('[trace] per-step ms:', [round((b[0] - a) * 1e3, 1) for a, b in zip([t0] + [x[0] for x in _tr[:-1]], _tr)], file=sys.stderr)
+        print('[trace] device allocs / frees / reserved MiB:', [(x[1], x[2], x[3]) for x in _tr], file=sys.stderr)
+        for name, evs in profiling._events.items():
+            print('[trace] {:>14s} ms:'.format(name), [round(a.elapsed_time(b), 1) for a, b in evs], file=sys.stderr)
     if graph_ev:
         graph_ev[1].record()
     torch.cuda.synchronize()

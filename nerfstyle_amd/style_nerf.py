@@ -92,13 +92,13 @@ class _field(Function):
                                               L.p(xyzs), M, L.p(m_dev), L.p(sigmas), L.p(rgbs), L.p(feats), None,
                                               L.stream()),
                     'field_forward')
-        ctx.feats = feats
-        ctx.perm = perm
         ctx.model = model
         ctx.m_dev = m_dev
         ctx.density_scale = density_scale
         ctx.sigma_only = sigma_only
-        ctx.save_for_backward(xyzs)
+        # feats (15.6 GB at a full-frame capacity) and perm go through save_for_backward, NOT ctx attributes: autograd
+        # drops saved tensors when backward() has run, attributes live as long as anything still holds the loss
+        ctx.save_for_backward(xyzs, feats, perm)
         if sigma_only:
             return sigmas
         return sigmas, rgbs
@@ -106,7 +106,7 @@ class _field(Function):
     @staticmethod
     def backward(ctx, grad_sigmas, grad_rgbs=None):
         model = ctx.model
-        (xyzs,) = ctx.saved_tensors
+        xyzs, feats, perm = ctx.saved_tensors
         M = xyzs.shape[0]
         dev = xyzs.device
         if grad_sigmas is None:
@@ -120,7 +120,7 @@ class _field(Function):
         ga = model.grad_arena
         tables = model._gather_tables()
         ws = None
-        if ctx.perm is not None:
+        if perm is not None:
             # [M][16] float4 of per-level encoder gradients for the spatially ordered table scatter (second kernel): 256 B
             # per sample SLOT (31 GB for a 122 M-slot capacity buffer), kept on the model and only ever grown -- the
             # caching allocator would otherwise be asked for the largest block of the step every step
@@ -134,10 +134,10 @@ class _field(Function):
                 return L.lib().nsr_field_backward(
                     ctypes.byref(desc), L.p(tables), L.p(model._mlp_flat()), L.p(xyzs), M, L.p(ctx.m_dev),
                     L.p(grad_sigmas), L.p(grad_rgbs), L.p(ga), ga.data_ptr() + model.table_elems * 4,
-                    int(model.train_density_table), int(model.train_color_table), L.p(ctx.feats), L.p(perm), L.p(wsp),
+                    int(model.train_density_table), int(model.train_color_table), L.p(feats), L.p(perm), L.p(wsp),
                     L.stream())
-            st = call(ctx.perm, ws)
-            if st == -2 and ctx.perm is not None:
+            st = call(perm, ws)
+            if st == -2 and perm is not None:
                 # NSR_ERR_UNSUPPORTED: a grid finer than the spatial scatter's LDS lattices hold (finest resolution above
                 # ~5 cells per 1/1024 block) -- nothing was launched; the fused run-tracker backward takes over
                 model._spatial_scatter_unsupported = True
