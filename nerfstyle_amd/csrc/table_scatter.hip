@@ -111,6 +111,9 @@ __device__ __forceinline__ void lat_flush_level(float4 *__restrict__ lat4, uint3
 // kernel-argument segment here would be a vector-memory load, and waiting for it means waiting for every atomic in flight.
 __device__ __forceinline__ void lat_flush_dispatch(float4 *__restrict__ lat, int fl, const LatState &st,
                                                    const NsrLevel *__restrict__ lds_lv, float *__restrict__ gt, int lane, bool td, bool tc) {
+#ifdef NSR_ABL_TS_NOFLUSH
+    return;
+#endif
     const uint32_t o0 = (uint32_t)__builtin_amdgcn_readlane((int)st.b0, fl * 4);
     if (o0 == LAT_NONE) return;
     const uint32_t o1 = (uint32_t)__builtin_amdgcn_readlane((int)st.b1, fl * 4);
@@ -212,10 +215,18 @@ struct TableScatterArgs {
 #ifndef NSR_TS_LDS_ATOMIC
 #define NSR_TS_LDS_ATOMIC 0
 #endif
+#ifndef NSR_TS_RING
+#define NSR_TS_RING 8           /* gradient rows in flight per wave (0: one-step-ahead prefetch, the r2 first version) */
+#endif
 #ifndef NSR_TS_UNROLL
 #define NSR_TS_UNROLL 4         /* 1 -> 31.7 ms, 2 -> 30.6, 4 -> 29.4, 8 -> 29.6 */
 #endif
 constexpr int TS_THREADS = NSR_TS_THREADS;
+#ifdef NSR_ABL_TS_NOGIN
+#define TS_GIN(v, ln) make_float4(1.0f, 2.0f, 3.0f, (float)(ln))
+#else
+#define TS_GIN(v, ln) a.gin[(size_t)(uint32_t)__builtin_amdgcn_readlane((int)(v), (ln)) * 16 + l]
+#endif
 static size_t ts_wave_bytes(uint32_t lat_slots) { return 256 + (size_t)lat_slots * 16; }
 
 __global__ void __launch_bounds__(TS_THREADS)
@@ -267,6 +278,13 @@ k_table_scatter(TableScatterArgs a) {
     uint32_t idx = fetch_idx(w_begin);
     uint32_t idx_next = w_begin + 1 < w_end ? fetch_idx(w_begin + 1) : idx;
     float x0 = a.xyzs[(size_t)idx * 3], x1 = a.xyzs[(size_t)idx * 3 + 1], x2 = a.xyzs[(size_t)idx * 3 + 2];
+#if NSR_TS_RING
+    // The per-level gradients of the next NSR_TS_RING samples, in registers: a 256-byte row gathered by sample index is a
+    // full HBM round trip (~1 us under load), far longer than a step, so a row is requested 8 steps before its use.
+    float4 gq[NSR_TS_RING];
+#pragma unroll
+    for (int i = 0; i < NSR_TS_RING; i++) gq[i] = TS_GIN(idx, i);
+#endif
 
     for (uint32_t tile = w_begin; tile < w_end; tile++) {
         // next tile's inputs: the permutation entry was fetched one tile ahead, so these loads depend on nothing in flight
@@ -285,13 +303,28 @@ k_table_scatter(TableScatterArgs a) {
         const uint32_t q0 = (uint32_t)fminf(fmaxf(u0 * kq, 0.0f), kq - 1.0f), q1 = (uint32_t)fminf(fmaxf(u1 * kq, 0.0f), kq - 1.0f),
                        q2 = (uint32_t)fminf(fmaxf(u2 * kq, 0.0f), kq - 1.0f);
         const uint32_t bkey = q0 | (q1 << LAT_KEY_BITS) | (q2 << (2 * LAT_KEY_BITS));
+#if NSR_TS_RING
+#pragma unroll 1
+        for (int part = 0; part < 16 / NSR_TS_RING; part++) {
+        // refills: the rest of this tile first, then the head of the next one (its permutation entries are already here)
+        const bool wrap = part == 16 / NSR_TS_RING - 1;
+        const uint32_t src = wrap ? idx_next : idx;
+        const int src_lane0 = wrap ? 0 : (part + 1) * NSR_TS_RING;
+#pragma unroll
+        for (int ri = 0; ri < NSR_TS_RING; ri++) {
+            const int step = part * NSR_TS_RING + ri;
+            const float4 gr = gq[ri];
+            do {
+            if (!((live16 >> step) & 1u)) break;                               // wave-uniform
+#else
         // the per-level gradients of a sample are fetched one step ahead of their use
-        float4 gr_next = a.gin[(size_t)(uint32_t)__builtin_amdgcn_readlane((int)idx, 0) * 16 + l];
+        float4 gr_next = TS_GIN(idx, 0);
 #pragma unroll NSR_TS_UNROLL
         for (int step = 0; step < 16; step++) {
             const float4 gr = gr_next;
-            if (step < 15) gr_next = a.gin[(size_t)(uint32_t)__builtin_amdgcn_readlane((int)idx, step + 1) * 16 + l];
+            if (step < 15) gr_next = TS_GIN(idx, step + 1);
             if (!((live16 >> step) & 1u)) continue;                            // wave-uniform
+#endif
             const uint32_t key = (uint32_t)__builtin_amdgcn_readlane((int)bkey, step);
             if (key != cur_key) {
                 // ---- the walk enters another block: re-anchor every level at the cell of the block's origin ----
@@ -360,11 +393,23 @@ k_table_scatter(TableScatterArgs a) {
             __hip_atomic_fetch_add(sf + 6, wB * gr.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
             __hip_atomic_fetch_add(sf + 7, wB * gr.w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
 #else
+#ifdef NSR_ABL_TS_NORMW
+            if (wA == 123.0f) slot[0] = gr;
+#else
             float4 va = slot[0], vb = slot[1];
             va.x = fmaf(wA, gr.x, va.x); va.y = fmaf(wA, gr.y, va.y); va.z = fmaf(wA, gr.z, va.z); va.w = fmaf(wA, gr.w, va.w);
             vb.x = fmaf(wB, gr.x, vb.x); vb.y = fmaf(wB, gr.y, vb.y); vb.z = fmaf(wB, gr.z, vb.z); vb.w = fmaf(wB, gr.w, vb.w);
             slot[0] = va;
             slot[1] = vb;
+#endif
+#endif
+#if NSR_TS_RING
+            } while (0);
+            // the slot's refill is issued AFTER the last use of its old value, so every ring slot stays in the same registers
+            // (a refill issued earlier gets other registers, and the copies at the loop edge wait for every load in flight)
+            asm volatile("" ::: "memory");
+            gq[ri] = TS_GIN(src, src_lane0 + ri);
+        }
 #endif
         }
         x0 = nx0; x1 = nx1; x2 = nx2;
