@@ -57,6 +57,7 @@ def parse():
     ap.add_argument('--compute-dtype', choices=['f16', 'bf16'], default='f16')
     ap.add_argument('--samples-cap', type=int, default=160, help='sample-buffer capacity in samples per ray')
     ap.add_argument('--sparsity-lambda', type=float, default=0.0, help='cfgs: --sparsity_lambda (0.01 in BASELINE configs[3])')
+    ap.add_argument('--fp32-loss', action='store_true', help='style stage: VGG + style loss in fp32 instead of autocast')
     ap.add_argument('--no-occ-update', action='store_true', help='leave the periodic occupancy update out of the step')
     ap.add_argument('--sort-samples', choices=['auto', 'on', 'off'], default='auto',
                     help="spatially ordered table scatter in the backward (nsr_sample_order): 'auto' = dense batches (>= 200 000 rays) only")
@@ -443,11 +444,14 @@ def run_style(args, dev, rank, world):
     style = torch.rand(3, H, W, device=dev, generator=g)                       # SingleImage(longer edge = max(W, H)), style.py:60-61
     seg = torch.randint(0, nc, (H, W), device=dev, generator=g)
     fx = VGG16FeatureExtractor(['relu3']).to(dev)
-    crit = StyleCriterion(fx, SemanticStyleLoss(['relu3'], clusters=seg), content_lambda=0.001, style_lambda=1.0)
+    # the reference evaluates the loss under autocast (enable_amp: true, style.py:182-184)
+    amp = None if args.fp32_loss else (torch.float16 if args.compute_dtype == 'f16' else torch.bfloat16)
+    crit = StyleCriterion(fx, SemanticStyleLoss(['relu3'], clusters=seg), content_lambda=0.001, style_lambda=1.0, amp_dtype=amp)
     crit.init_style(style, num_classes=nc)
     opt = FusedAdam(model, lr=0.1, keywords=['x_color_embedder'])
     loss_scale = 65536.0 if args.compute_dtype == 'f16' else 1.0
     n_patches = len(patch_list(W, H, 200))
+    patch_graphs = {} if args.graph else None                                  # --graph: one hipGraph per patch shape in pass 2
     total_samples = torch.zeros(1, dtype=torch.int64, device=dev)
 
     def step(it):
@@ -460,7 +464,7 @@ def run_style(args, dev, rank, world):
         def image_loss(rgb, classes):
             return crit(rgb, targets[frame], classes, frame_key=frame, it=it)[0]
         loss, _ = deferred_backprop_step(r, poses[frame], image_loss, patch_size=200, loss_scale=loss_scale, rank=rank, world=world,
-                                         with_classes=True)
+                                         with_classes=True, patch_graphs=patch_graphs)
         opt.step(grad_scale=loss_scale)
         return loss
 
@@ -499,7 +503,7 @@ def run_style(args, dev, rank, world):
         'scaling': 'strong', 'vs_baseline': None, 'dtype': args.compute_dtype, 'data': 'synthetic',
         'config': {
             'workload': "LLFF '{}' stylisation stage, {}x{} frame per iteration: 1 full-frame no-grad pass + VGG16-relu3 content / "
-                        "semantic-NNFM loss (PyTorch) + {} deferred-backprop patches of 200x200, colour table only, max_steps {}; random "
+                        "semantic-NNFM loss (PyTorch, " + ('fp32' if args.fp32_loss else 'autocast ' + args.compute_dtype) + ") + {} deferred-backprop patches of 200x200, colour table only, max_steps {}; random "
                         "seeded VGG weights, style image and segment maps (none exist offline)".format(args.scene, W, H, n_patches, rcfg.max_steps),
             'rays_per_step': W * H, 'patches': n_patches, 'max_steps': rcfg.max_steps, 'num_classes': nc,
             'table_dtype': args.table_dtype, 'mfma_dtype': args.compute_dtype,

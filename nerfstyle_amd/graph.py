@@ -96,3 +96,65 @@ class GraphedRenderStep:
     def counter(self):
         """device-side (samples, rays) counter of the captured march"""
         return self._counter
+
+
+class GraphedPatchBackward:
+    """One patch of the deferred back-propagation (trainers/style.py:189-198) as a graph: render `n_rays` pixels of a frame
+    with autograd and back-propagate a given d loss / d rgb into model.arena.grad.
+
+        g = GraphedPatchBackward(renderer, n_rays); g(pose, pix, grad)      # pix [n_rays] positions in the frame, grad [n_rays, 3]
+
+    A 1008x756 iteration re-renders 24 patches, ~40 launches each plus their host-side bookkeeping: eager, the GPU waits for
+    the host between kernels (the kernel-event spans of the patch loop are 40 % longer than the kernels).  Patches of
+    the same size share one graph (pose, pixel positions and the gradient are static buffers refilled before a replay).
+    The renderer must not update its occupancy grid in this stage (StyleTrainer never does)."""
+
+    def __init__(self, renderer: Renderer, n_rays: int, dense: bool = True, warmup: int = 1):
+        self.r = renderer
+        dev = renderer.device
+        self.pose = torch.zeros(4, 4, dtype=torch.float32, device=dev)
+        self.pose[:3, :3] = torch.eye(3, device=dev)
+        self.pix = torch.arange(n_rays, dtype=torch.int64, device=dev)
+        self.grad = torch.zeros(n_rays, 3, dtype=torch.float32, device=dev)
+        self.dense = dense
+        self.graph = None
+        self._warmup = warmup
+
+    def _body(self):
+        keep = self.r.update_occ
+        self.r.update_occ = False
+        try:
+            out = self.r.render(self.pose, None, training=True, pix_subset=self.pix, dense=self.dense)
+        finally:
+            self.r.update_occ = keep
+        out['rgb_map'].backward(self.grad)
+
+    def capture(self):
+        """The static buffers must hold a real patch: the warm-up passes run on them, and their gradient is removed again."""
+        model = self.r.model
+        model._ensure_grad()
+        if model.table_dtype == torch.float16:
+            model._gather_tables()
+        saved = model.arena.grad.clone()
+        s = torch.cuda.Stream(device=self.r.device)
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(self._warmup):
+                self._body()
+        torch.cuda.current_stream().wait_stream(s)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self._body()
+        model.arena.grad.copy_(saved)
+        return self
+
+    def __call__(self, pose: torch.Tensor, pix: torch.Tensor, grad: torch.Tensor) -> None:
+        self.pose.copy_(pose)
+        self.pix.copy_(pix)
+        self.grad.copy_(grad)
+        if self.graph is None:
+            self.capture()
+        m = self.r.model
+        if m.table_dtype == torch.float16 and m._half_version != m.arena._version:
+            m._gather_tables()
+        self.graph.replay()

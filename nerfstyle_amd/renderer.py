@@ -231,6 +231,12 @@ class Renderer(torch.nn.Module):
     def _use_spatial_order(self, n_rays: int, dense: bool) -> bool:
         if getattr(self.model, '_spatial_scatter_unsupported', False):
             return False                 # learnt from a backward that fell back (style_nerf._field.backward)
+        if torch.cuda.is_current_stream_capturing():
+            # rocPRIM's radix sort resets its histogram / look-back / block-id state with hipMemsetAsync; captured into a
+            # hipGraph those resets do not take effect on replay (ROCm 7.2: first replay on fresh memory correct, the second
+            # one faults inside radix_sort_onesweep_iteration -- tools/exp_patch_graph.py stage 1).  Captured steps
+            # therefore use the ray-order run tracker, which is the better scatter at graph-sized batches anyway.
+            return False
         if self.sort_samples != 'auto':
             return bool(self.sort_samples)
         return n_rays >= self.sort_min_rays or (dense and n_rays >= self.sort_min_dense_rays)
@@ -343,8 +349,8 @@ class Renderer(torch.nn.Module):
         return image, depth, classes
 
     def render(self, pose, image=None, patch: Optional[Box2D] = None, num_rays: Optional[int] = None,
-               training: bool = False, pix_subset=None) -> Dict[str, torch.Tensor]:
-        """renderer.py:295-313"""
+               training: bool = False, pix_subset=None, dense: Optional[bool] = None) -> Dict[str, torch.Tensor]:
+        """renderer.py:295-313.  `dense` overrides the guess below for callers that pass a patch as `pix_subset`."""
         output = {}
         precrop_frac = self.precrop_frac if self._use_precrop else 1.
         rays, output['target'] = generate_rays(pose, self.intr, image, patch=patch, precrop=precrop_frac, bsize=num_rays,
@@ -352,7 +358,8 @@ class Renderer(torch.nn.Module):
                                                device=self.device)
         render_fn = self.render_train if training else self.render_test
         # a full frame, a patch or a centre crop is a dense pixel set: neighbouring rays share hash-table rows
-        dense = pix_subset is None and num_rays is None
+        if dense is None:
+            dense = pix_subset is None and num_rays is None
         output['rgb_map'], output['trans_map'], output['classes'] = render_fn(rays, dense=dense)
         return output
 

@@ -125,10 +125,13 @@ class _field(Function):
             # per sample SLOT (31 GB for a 122 M-slot capacity buffer), kept on the model and only ever grown -- the
             # caching allocator would otherwise be asked for the largest block of the step every step
             need = int(L.lib().nsr_field_backward_workspace_bytes(M, 1)) // 4
-            ws = getattr(model, '_bwd_ws', None)
-            if ws is None or ws.device != dev or ws.numel() < need:
-                model._bwd_ws = None
-                ws = model._bwd_ws = torch.empty(need, dtype=torch.float32, device=dev)
+            if torch.cuda.is_current_stream_capturing():
+                ws = torch.empty(need, dtype=torch.float32, device=dev)      # graph-owned: a captured pointer must never dangle
+            else:
+                ws = getattr(model, '_bwd_ws', None)
+                if ws is None or ws.device != dev or ws.numel() < need:
+                    model._bwd_ws = None
+                    ws = model._bwd_ws = torch.empty(need, dtype=torch.float32, device=dev)
         with profiling.timed('field_bwd'):
             def call(perm, wsp):
                 return L.lib().nsr_field_backward(
@@ -345,12 +348,16 @@ class StyleTCNerf(nn.Module):
         """nsr_sample_order: Morton-order permutation of the samples [M,3] (int32 tensor [M], a uint32 bit pattern)."""
         M = xyzs.shape[0]
         dev = xyzs.device
-        key = (M, str(dev))
-        if getattr(self, '_order_key', None) != key:
-            nbytes = int(L.lib().nsr_sample_order_workspace_bytes(M))
-            self._order_ws = torch.empty((nbytes + 3) // 4 + 64, dtype=torch.int32, device=dev)
-            self._order_key = key
-        ws = self._order_ws
+        need = (int(L.lib().nsr_sample_order_workspace_bytes(M)) + 3) // 4 + 64
+        if torch.cuda.is_current_stream_capturing():
+            # a captured launch bakes its pointers in: the workspace must belong to the graph's own pool, not to a cache
+            # on the model that a later call with another M replaces
+            ws = torch.empty(need, dtype=torch.int32, device=dev)
+        else:
+            ws = getattr(self, '_order_ws', None)
+            if ws is None or ws.device != dev or ws.numel() < need:
+                self._order_ws = None
+                ws = self._order_ws = torch.empty(need, dtype=torch.int32, device=dev)
         ws_ptr = (ws.data_ptr() + 255) & ~255
         perm = torch.empty(M, dtype=torch.int32, device=dev)
         if getattr(self, '_bbox_host', None) is None:

@@ -31,10 +31,18 @@ class StyleCriterion:
     content_lambda 0.001, style_lambda 1.0).  The features of the fixed images are computed once and cached (the
     reference re-extracts target and style features every iteration, style.py:88-89)."""
 
-    def __init__(self, fx, style_loss, content_lambda: float = 0.001, style_lambda: float = 1.0, content_feat: str = 'relu3'):
+    def __init__(self, fx, style_loss, content_lambda: float = 0.001, style_lambda: float = 1.0, content_feat: str = 'relu3',
+                 amp_dtype=None):
+        """amp_dtype: torch.float16 / torch.bfloat16 runs the loss under torch.autocast, as the reference does with
+        enable_amp (cfgs/training/default.yaml:16, style.py:182-184: convolutions and the feature products in half
+        precision, reductions in fp32); None = fp32."""
         self.fx, self.style_loss = fx, style_loss
         self.content_lambda, self.style_lambda, self.content_feat = content_lambda, style_lambda, content_feat
+        self.amp_dtype = amp_dtype
         self._target_feats = {}
+
+    def _autocast(self, device):
+        return torch.autocast(device_type=device.type, dtype=self.amp_dtype, enabled=self.amp_dtype is not None)
 
     @torch.no_grad()
     def init_style(self, style_image: torch.Tensor, num_classes: int):
@@ -49,11 +57,12 @@ class StyleCriterion:
 
     def __call__(self, rgb_hw3: torch.Tensor, target_chw: torch.Tensor, classes_hwc: torch.Tensor, frame_key=None, it: int = 0):
         """rgb_hw3 [H,W,3] (requires_grad), target_chw [3,H,W], classes_hwc [H,W,nc] logits -> (total, content, style)"""
-        rgb_feats = self.fx(rgb_hw3.permute(2, 0, 1))
-        tgt = self.target_features(frame_key, target_chw) if frame_key is not None else self.fx(target_chw)[self.content_feat]
-        preds = torch.argmax(classes_hwc, dim=-1)                                   # style.py:85
-        content = F.mse_loss(rgb_feats[self.content_feat], tgt) * self.content_lambda
-        style = self.style_loss(rgb_feats, None, preds, it) * self.style_lambda
+        with self._autocast(rgb_hw3.device):
+            rgb_feats = self.fx(rgb_hw3.permute(2, 0, 1))
+            tgt = self.target_features(frame_key, target_chw) if frame_key is not None else self.fx(target_chw)[self.content_feat]
+            preds = torch.argmax(classes_hwc, dim=-1)                                   # style.py:85
+            content = F.mse_loss(rgb_feats[self.content_feat], tgt) * self.content_lambda
+            style = self.style_loss(rgb_feats, None, preds, it) * self.style_lambda
         return content + style, content.detach(), style.detach()
 
 
@@ -103,10 +112,13 @@ def _all_gather_ragged(chunks, part):
 
 
 def deferred_backprop_step(renderer, pose, image_loss: Callable, patch_size: int = 200, loss_scale: float = 1.0, rank: int = 0,
-                           world: int = 1, only_color_table: bool = True, with_classes: bool = False):
+                           world: int = 1, only_color_table: bool = True, with_classes: bool = False,
+                           patch_graphs: Optional[dict] = None):
     """One stylisation iteration up to (not including) the optimiser step.  `image_loss` maps rgb [H, W, 3]
     (requires_grad) -- and, with_classes, the class logits [H, W, nc] of the same pass -- to a scalar.
-    Gradients accumulate into model.arena.grad.  Returns (loss value, rgb_map of pass 1)."""
+    Gradients accumulate into model.arena.grad.  Returns (loss value, rgb_map of pass 1).
+    patch_graphs: a dict the caller keeps across iterations; when given, pass 2 replays one hipGraph per patch shape
+    (graph.GraphedPatchBackward) instead of launching every patch's kernels from the host."""
     W, H = renderer.intr.size()
     if with_classes:
         rgb, classes = render_full_frame(renderer, pose, rank, world, with_classes=True)
@@ -120,9 +132,19 @@ def deferred_backprop_step(renderer, pose, image_loss: Callable, patch_size: int
     patches = patch_list(W, H, patch_size)
     b, e = P.shard_bounds(len(patches), rank, world)
     for box in patches[b:e]:
-        out = renderer.render(pose, None, patch=box, training=True)
         g = grad_map[box.y:box.y + box.h, box.x:box.x + box.w].reshape(-1, 3)
-        out['rgb_map'].backward(g)                         # style.py:196-198
+        if patch_graphs is None:
+            out = renderer.render(pose, None, patch=box, training=True)
+            out['rgb_map'].backward(g)                     # style.py:196-198
+            continue
+        from .graph import GraphedPatchBackward
+        rows = torch.arange(box.y, box.y + box.h, device=renderer.device)
+        cols = torch.arange(box.x, box.x + box.w, device=renderer.device)
+        pix = (rows[:, None] * W + cols[None, :]).reshape(-1)              # positions in the row-major frame
+        key = (box.w * box.h, W, H)
+        if key not in patch_graphs:
+            patch_graphs[key] = GraphedPatchBackward(renderer, box.w * box.h, dense=True)
+        patch_graphs[key](torch.as_tensor(pose, dtype=torch.float32, device=renderer.device), pix, g)
     if world > 1:
         P.sync_gradients(renderer.model, only_color_table=only_color_table)
     return loss.detach(), rgb.detach()

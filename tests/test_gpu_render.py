@@ -655,3 +655,37 @@ def test_bf16_graph_replayed_training_step(O, dev):
         opt.step()
     assert r.local_step == 18 and int(r._occ_state[0]) == 2 and np.all(np.isfinite(losses))
     assert int(r.density_bitfield.count_nonzero()) > 0
+
+
+def test_graphed_patch_backward_equals_eager(O, dev):
+    """stylize.deferred_backprop_step with patch_graphs (graph.GraphedPatchBackward: one hipGraph per patch shape) leaves
+    the same colour-table gradient as the eager patch loop (trainers/style.py:189-198), on two frames -- the second
+    iteration only replays.  504x378 frame, 200x200 patches: 6 patches of 4 different shapes."""
+    from nerfstyle_amd.optim import FusedAdam
+    from nerfstyle_amd.stylize import deferred_backprop_step
+    r, ref, poses, intr, bits = _setup(dev, cap=256)
+    r.cfg.max_steps = 512
+    m = r.model
+    FusedAdam(m, lr=0.1, keywords=['x_color_embedder'])         # colour table only, as in the stylisation stage
+    W, H = intr.size()
+    tgt = torch.rand(H, W, 3, generator=torch.Generator().manual_seed(5)).to(dev)
+
+    def image_loss(rgb):
+        return torch.mean((rgb - tgt) ** 2)
+
+    def run(graphs, pose):
+        m._ensure_grad()
+        m.arena.grad.zero_()
+        deferred_backprop_step(r, pose, image_loss, patch_size=200, loss_scale=1024.0, patch_graphs=graphs)
+        return m.arena.grad.clone()
+
+    graphs = {}
+    for it in (0, 3):
+        pose = torch.tensor(poses[it], device=dev)
+        g_eager = run(None, pose)
+        g_graph = run(graphs, pose)
+        assert float(g_eager.abs().sum()) > 0
+        assert rel_l2(g_graph.cpu().numpy(), g_eager.cpu().numpy()) < 1e-5, it
+        gt = g_graph[:m.table_elems].view(m.rows, 2, 2)
+        assert float(gt[:, 0].abs().max()) == 0.0 and float(gt[:, 1].abs().max()) > 0.0
+    assert len(graphs) == 4

@@ -65,3 +65,30 @@ def test_semantic_style_loss_plain_and_matched(golden):
     a, _ = Ls.nearest_style_index(f1, f2, chunk=64)
     b, _ = Ls.nearest_style_index(f1, f2, chunk=100000)
     assert torch.equal(a, b) and torch.equal(a, torch.argmin(1 - f1 @ f2.T, dim=1))
+
+
+def test_grouped_matching_equals_masked_search():
+    """nearest_style_index groups positions by cluster instead of masking a full distance matrix: same arg-min as the masked
+    form (loss.py:201-206), including unrestricted rows (-1), unlabelled style positions (-1) and a class whose cluster is empty."""
+    from nerfstyle_amd import losses as Ls
+    g = torch.Generator().manual_seed(3)
+    N1, N2, C, K = 301, 257, 24, 4
+    f1 = torch.nn.functional.normalize(torch.randn(N1, C, generator=g), dim=1)
+    f2 = torch.nn.functional.normalize(torch.randn(N2, C, generator=g), dim=1)
+    rc = torch.randint(-1, K, (N1,), generator=g)
+    sc = torch.randint(-1, K - 1, (N2,), generator=g)            # cluster K-1 has no style position at all
+    idx, valid = Ls.nearest_style_index(f1, f2, rc, sc, chunk=64)
+    d = 1.0 - f1 @ f2.T
+    allowed = (sc[None, :] == rc[:, None]) | (rc[:, None] < 0)
+    ref_valid = allowed.any(dim=1)
+    ref_idx = torch.argmin(d.masked_fill(~allowed, float('inf')), dim=1)
+    assert torch.equal(valid, ref_valid)
+    assert (~ref_valid).sum() > 0 and (rc < 0).sum() > 0
+    assert torch.equal(idx[ref_valid], ref_idx[ref_valid])
+    # precomputed groups give the same answer
+    groups = [torch.nonzero(sc == k)[:, 0] for k in range(K)]
+    idx2, valid2 = Ls.nearest_style_index(f1, f2, rc, sc, chunk=1000, style_groups=groups)
+    assert torch.equal(idx2[ref_valid], ref_idx[ref_valid]) and torch.equal(valid2, ref_valid)
+    # no clusters: plain nearest neighbour
+    idx3, _ = Ls.nearest_style_index(f1, f2)
+    assert torch.equal(idx3, torch.argmin(d, dim=1))
