@@ -99,15 +99,18 @@ class GraphedRenderStep:
 
 
 class GraphedPatchBackward:
-    """One patch of the deferred back-propagation (trainers/style.py:189-198) as a graph: render `n_rays` pixels of a frame
-    with autograd and back-propagate a given d loss / d rgb into model.arena.grad.
+    """One patch of the deferred back-propagation (trainers/style.py:189-198) as TWO graphs with the sample sort between them:
+    render `n_rays` pixels of a frame with autograd and back-propagate a given d loss / d rgb into model.arena.grad.
 
         g = GraphedPatchBackward(renderer, n_rays); g(pose, pix, grad)      # pix [n_rays] positions in the frame, grad [n_rays, 3]
 
-    A 1008x756 iteration re-renders 24 patches, ~40 launches each plus their host-side bookkeeping: eager, the GPU waits for
-    the host between kernels (the kernel-event spans of the patch loop are 40 % longer than the kernels).  Patches of
-    the same size share one graph (pose, pixel positions and the gradient are static buffers refilled before a replay).
-    The renderer must not update its occupancy grid in this stage (StyleTrainer never does)."""
+    A 1008x756 iteration re-renders 24 patches, ~45 launches each plus their host-side bookkeeping: eager, the GPU waits for
+    the host between kernels (the kernel-event spans of the patch loop are 40 % longer than the kernels).  Graph 1 = ray
+    generation + march + compaction; then, for dense patches, the spatial order of the samples is computed EAGERLY (rocPRIM's
+    radix sort does not survive hipGraph replay, Renderer._use_spatial_order) into a static permutation buffer; graph 2 =
+    fused field + composite + their backward.  Patches of the same size share the graphs (pose, pixel positions and the
+    gradient are static buffers refilled before a replay).  The renderer must not update its occupancy grid in this stage
+    (StyleTrainer never does)."""
 
     def __init__(self, renderer: Renderer, n_rays: int, dense: bool = True, warmup: int = 1):
         self.r = renderer
@@ -116,18 +119,31 @@ class GraphedPatchBackward:
         self.pose[:3, :3] = torch.eye(3, device=dev)
         self.pix = torch.arange(n_rays, dtype=torch.int64, device=dev)
         self.grad = torch.zeros(n_rays, 3, dtype=torch.float32, device=dev)
-        self.dense = dense
-        self.graph = None
+        self.sorted = renderer._use_spatial_order(n_rays, dense)
+        self.perm = torch.empty(renderer.sample_capacity(n_rays), dtype=torch.int32, device=dev) if self.sorted else None
+        self.mt = None
+        self.g_march = self.g_shade = None
         self._warmup = warmup
 
-    def _body(self):
-        keep = self.r.update_occ
-        self.r.update_occ = False
+    def _march(self):
+        from .rays import generate_rays
+        r = self.r
+        keep = r.update_occ
+        r.update_occ = False               # a private device-side counter, no step bookkeeping inside the graph
         try:
-            out = self.r.render(self.pose, None, training=True, pix_subset=self.pix, dense=self.dense)
+            rays, _ = generate_rays(self.pose, r.intr, None, camera_flip=r.cfg.flip_camera, pix_subset=self.pix, device=r.device)
+            self.mt = r.march_train(rays)
         finally:
-            self.r.update_occ = keep
-        out['rgb_map'].backward(self.grad)
+            r.update_occ = keep
+
+    def _order(self):
+        if self.sorted:
+            mt = self.mt
+            self.r.model.sample_order(mt['xyzs'], mt['counter'], self.r._sort_prefix(mt['M'], mt['counter']), out=self.perm)
+
+    def _shade(self):
+        image, _, _ = self.r.shade_train(self.mt, self.perm)
+        image.backward(self.grad)
 
     def capture(self):
         """The static buffers must hold a real patch: the warm-up passes run on them, and their gradient is removed again."""
@@ -140,11 +156,17 @@ class GraphedPatchBackward:
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
             for _ in range(self._warmup):
-                self._body()
+                self._march()
+                self._order()
+                self._shade()
         torch.cuda.current_stream().wait_stream(s)
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self._body()
+        self.g_march = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.g_march):
+            self._march()
+        # graph 2 reads graph 1's outputs (kept alive by self.mt, so their memory stays reserved for graph 1) and self.perm
+        self.g_shade = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.g_shade):
+            self._shade()
         model.arena.grad.copy_(saved)
         return self
 
@@ -152,9 +174,12 @@ class GraphedPatchBackward:
         self.pose.copy_(pose)
         self.pix.copy_(pix)
         self.grad.copy_(grad)
-        if self.graph is None:
+        if self.g_march is None:
             self.capture()
         m = self.r.model
         if m.table_dtype == torch.float16 and m._half_version != m.arena._version:
             m._gather_tables()
-        self.graph.replay()
+        self.g_march.replay()
+        self._order()
+        self.g_shade.replay()
+        self.r._last_counter = self.mt['counter']

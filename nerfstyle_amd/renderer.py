@@ -199,9 +199,18 @@ class Renderer(torch.nn.Module):
         return n_rays * per_ray
 
     def render_train(self, rays: RayBatch, **kwargs):
-        """renderer.py:196-235 -> (image [N,3], depth [N], classes [N,nc])"""
+        """renderer.py:196-235 -> (image [N,3], depth [N], classes [N,nc]).  Three stages that graph.GraphedPatchBackward
+        also drives one by one: march (sync-free), optional spatial order of the samples, shade (field + composite)."""
         if self.update_occ and (self.local_step % self.cfg.update_iter == 0):
             self.update_state()
+        mt = self.march_train(rays)
+        perm = None
+        if torch.is_grad_enabled() and self._use_spatial_order(mt['N'], bool(kwargs.get('dense', False))):
+            perm = self.model.sample_order(mt['xyzs'], mt['counter'], self._sort_prefix(mt['M'], mt['counter']))
+        return self.shade_train(mt, perm)
+
+    def march_train(self, rays: RayBatch) -> dict:
+        """near/far + occupancy-grid march + compaction: capacity-sized sample buffers, device-side counts."""
         nears, fars = raymarching.near_far_from_aabb(rays.origins, rays.dirs, self.aabb, self.cfg.min_near)
         if self.update_occ:
             counter = self.step_counter[self.local_step % STEP_CTR_SIZE]
@@ -217,25 +226,29 @@ class Renderer(torch.nn.Module):
         xyzs, _, deltas, rays_info = raymarching.march_rays_train_nosync(
             rays.origins, rays.dirs, self.bound, self.march_bitfield, self.cascade, self.cfg.grid_size, nears, fars,
             M, counter, 0., self.cfg.max_steps)
-        perm = None
-        if torch.is_grad_enabled() and self._use_spatial_order(N, bool(kwargs.get('dense', False))):
-            perm = self.model.sample_order(xyzs, counter, self._sort_prefix(M, counter))
-        sigmas, rgbs = self.model.field(xyzs, sigma_only=False, m_dev=counter, density_scale=self.cfg.density_scale, perm=perm)
-        weights_sum, depth, image = _composite_train_nosync(sigmas, rgbs, deltas, rays_info, self.cfg.t_thresh)
+        return {'N': N, 'M': M, 'nears': nears, 'fars': fars, 'counter': counter, 'xyzs': xyzs, 'deltas': deltas,
+                'rays_info': rays_info}
+
+    def shade_train(self, mt: dict, perm=None):
+        """fused field on the marched samples + train composite + the epilogue of renderer.py:225-233"""
+        sigmas, rgbs = self.model.field(mt['xyzs'], sigma_only=False, m_dev=mt['counter'], density_scale=self.cfg.density_scale,
+                                        perm=perm)
+        weights_sum, depth, image = _composite_train_nosync(sigmas, rgbs, mt['deltas'], mt['rays_info'], self.cfg.t_thresh)
         classes = image[:, 3:]
         image = image[:, :3]
         image = image + (1 - weights_sum).unsqueeze(-1)
-        depth = torch.clamp(depth - nears, min=0) / (fars - nears)
+        depth = torch.clamp(depth - mt['nears'], min=0) / (mt['fars'] - mt['nears'])
         return image, depth, classes
 
     def _use_spatial_order(self, n_rays: int, dense: bool) -> bool:
         if getattr(self.model, '_spatial_scatter_unsupported', False):
             return False                 # learnt from a backward that fell back (style_nerf._field.backward)
         if torch.cuda.is_current_stream_capturing():
-            # rocPRIM's radix sort resets its histogram / look-back / block-id state with hipMemsetAsync; captured into a
-            # hipGraph those resets do not take effect on replay (ROCm 7.2: first replay on fresh memory correct, the second
-            # one faults inside radix_sort_onesweep_iteration -- tools/exp_patch_graph.py stage 1).  Captured steps
-            # therefore use the ray-order run tracker, which is the better scatter at graph-sized batches anyway.
+            # rocPRIM's radix sort does not survive hipGraph replay on ROCm 7.2 / MI355X: captured alone, the first replay
+            # is correct and the second one faults inside radix_sort_onesweep_iteration, also when its temporary storage
+            # is cleared by a kernel first (tools/exp_patch_graph.py stage 1).  A captured step therefore never sorts:
+            # it uses the ray-order run tracker, or gets its permutation from an eager sort between two graphs
+            # (graph.GraphedPatchBackward).
             return False
         if self.sort_samples != 'auto':
             return bool(self.sort_samples)

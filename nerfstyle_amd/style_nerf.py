@@ -344,8 +344,9 @@ class StyleTCNerf(nn.Module):
         want_feats = bool(self.save_features and torch.is_grad_enabled() and self.arena.requires_grad and not sigma_only)
         return _field.apply(pts, self.arena, self, sigma_only, m_dev, density_scale, want_feats, perm)
 
-    def sample_order(self, xyzs, m_dev=None, sort_prefix=None):
-        """nsr_sample_order: Morton-order permutation of the samples [M,3] (int32 tensor [M], a uint32 bit pattern)."""
+    def sample_order(self, xyzs, m_dev=None, sort_prefix=None, out=None):
+        """nsr_sample_order: Morton-order permutation of the samples [M,3] (int32 tensor [M], a uint32 bit pattern;
+        written into `out` when given)."""
         M = xyzs.shape[0]
         dev = xyzs.device
         need = (int(L.lib().nsr_sample_order_workspace_bytes(M)) + 3) // 4 + 64
@@ -359,7 +360,8 @@ class StyleTCNerf(nn.Module):
                 self._order_ws = None
                 ws = self._order_ws = torch.empty(need, dtype=torch.int32, device=dev)
         ws_ptr = (ws.data_ptr() + 255) & ~255
-        perm = torch.empty(M, dtype=torch.int32, device=dev)
+        perm = torch.empty(M, dtype=torch.int32, device=dev) if out is None else out
+        assert perm.dtype == torch.int32 and perm.numel() == M and perm.is_contiguous() and perm.device == dev
         if getattr(self, '_bbox_host', None) is None:
             self._desc()
         mn, sz = self._bbox_host
