@@ -689,3 +689,41 @@ def test_graphed_patch_backward_equals_eager(O, dev):
         gt = g_graph[:m.table_elems].view(m.rows, 2, 2)
         assert float(gt[:, 0].abs().max()) == 0.0 and float(gt[:, 1].abs().max()) > 0.0
     assert len(graphs) == 4
+
+
+def test_style_criterion_autocast_close_to_fp32(dev):
+    """StyleCriterion(amp_dtype=f16 / bf16) -- the reference's enable_amp (style.py:182-184) -- against the fp32 criterion on
+    the same 504x378 frame.  Whole loss: value within 1 % (bf16: 3 %), gradient finite and of the same size (on random images and random
+    VGG weights the style features are near-equidistant, so most nearest-neighbour choices flip in half precision and the
+    gradient DIRECTION of the style term is not comparable).  Content term alone (no matching): gradient cosine > 0.99."""
+    from nerfstyle_amd.losses import SemanticStyleLoss
+    from nerfstyle_amd.stylize import StyleCriterion
+    from nerfstyle_amd.vgg import VGG16FeatureExtractor
+    g = torch.Generator().manual_seed(11)
+    H, W = 378, 504
+    target = torch.rand(3, H, W, generator=g).to(dev)
+    style = torch.rand(3, H, W, generator=g).to(dev)
+    seg = torch.randint(0, 5, (H, W), generator=g)
+    classes = torch.rand(H, W, 5, generator=g).to(dev)
+    rgb0 = torch.rand(H, W, 3, generator=g).to(dev)
+    fx = VGG16FeatureExtractor(['relu3']).to(dev)
+
+    def run(amp, style_lambda):
+        crit = StyleCriterion(fx, SemanticStyleLoss(['relu3'], clusters=seg, matching=[0, 1, 2, 3, 4]), content_lambda=0.001,
+                              style_lambda=style_lambda, amp_dtype=amp)
+        crit.init_style(style, num_classes=5)
+        rgb = rgb0.clone().requires_grad_(True)
+        loss = crit(rgb, target, classes)[0]
+        (loss * 65536.0).backward()             # the GradScaler's initial scale (style.py:186): f16 activations' gradients underflow without it
+        assert loss.dtype == torch.float32 and rgb.grad.dtype == torch.float32
+        return float(loss.detach()), rgb.grad.flatten().double() / 65536.0
+
+    for style_lambda in (1.0, 0.0):
+        l32, g32 = run(None, style_lambda)
+        for amp, tol_cos, tol_loss in ((torch.float16, 0.99, 1e-2), (torch.bfloat16, 0.95, 3e-2)):
+            l, gv = run(amp, style_lambda)
+            assert abs(l - l32) < tol_loss * abs(l32), (amp, style_lambda, l, l32)
+            assert bool(torch.isfinite(gv).all()) and 0.7 < float(gv.norm() / g32.norm()) < 1.4, (amp, style_lambda)
+            if style_lambda == 0.0:
+                cos = float(torch.dot(gv, g32) / (gv.norm() * g32.norm()))
+                assert cos > tol_cos, (amp, cos)
