@@ -30,6 +30,12 @@
 #define NSR_BWD_PKMAX false
 #endif
 #endif
+#ifndef NSR_BWD_WQ
+#define NSR_BWD_WQ 0               /* straight-order MLP section with queued weight fragments (GOUT unit) */
+#endif
+#ifndef NSR_BWD_EARLY_NEXT
+#define NSR_BWD_EARLY_NEXT 0
+#endif
 #ifndef NSR_BWD_NET_ORDER
 #ifdef NSR_BWD_TU_GOUT
 #define NSR_BWD_NET_ORDER 0          /* with PKMAX: 13.0 ms in the straight order, 13.45 ms net by net */
@@ -519,6 +525,12 @@ k_field_bwd(FieldBwdArgs b) {
 #define NSR_TICK(var) do { } while (0)
 #define NSR_TACC(i, a, c) do { } while (0)
 #endif
+#if NSR_BWD_WQ
+    // weight-fragment queue of the MLP section (mfma_tiles.h, mm_queue32): holds the next layer's first four fragments
+    s8v wq[4];
+    s4v wq16[4];
+    mm_queue32<4>(wq, wl + FW_D1, lane);
+#endif
     for (uint32_t tile = w_begin; tile < w_end; tile++) {
         NSR_TICK(tk0);
 #ifdef NSR_ABL_STATS
@@ -531,6 +543,15 @@ k_field_bwd(FieldBwdArgs b) {
         // GOUT writes no LDS inside this loop, so the compiler would hoist the (loop-invariant) weight-fragment LDS reads
         // out of it and spill them all -- 220 VGPRs to scratch, reloaded every tile.  The barrier keeps them where they are.
         if (GOUT) asm volatile("" ::: "memory");
+#if NSR_BWD_EARLY_NEXT
+        // Every member of `cur` is made resident HERE, before this tile issues its own stores and loads: left to its first
+        // use, a member's wait comes after them and -- one in-order vmcnt, loop-carried -- is emitted as vmcnt(0): the wave
+        // then sits out the round trip of the loads it issued a moment ago (seen in the ISA: vmcnt(0) in front of the first
+        // MFMA that reads cur.xc).  The loads of `cur` are a whole tile old at this point.
+        if (GOUT)
+            asm volatile("" :: "v"(cur.x0), "v"(cur.x1), "v"(cur.x2), "v"(cur.gsig), "v"(cur.grgb[0]), "v"(cur.grgb[1]),
+                         "v"(cur.grgb[2]), "v"(cur.grgb[3]), "v"(cur.xd), "v"(cur.xc));
+#endif
         const float u0 = valid ? field_unit(cur.x0, a.bmin[0], a.bsize[0]) : 0.f;
         const float u1 = valid ? field_unit(cur.x1, a.bmin[1], a.bsize[1]) : 0.f;
         const float u2 = valid ? field_unit(cur.x2, a.bmin[2], a.bsize[2]) : 0.f;
@@ -545,6 +566,9 @@ k_field_bwd(FieldBwdArgs b) {
 
         // paced drain of the previous tile's records: SCQ_PACE(n) issues <= n atomic wave-instructions
 #define SCQ_PACE(n) do { if (!GOUT) scq_pace(q, gt1, lane, td, tc, (n), false); } while (0)
+        // (value-initialised, NOT a copy of cur: copying cur's not-yet-used members here would wait for their loads, and
+        // -- one in-order vmcnt -- for the gradient stores issued in between)
+        TileIn nxt{};
 #if NSR_BWD_NET_ORDER
         // ================= one net at a time: forward recompute -> dgrad -> wgrad, then its activations are dead ===========
         // (The straight order -- all four forwards, then all backwards -- keeps hd, hk, hc, hr1, hr2 alive together: 40
@@ -678,6 +702,160 @@ k_field_bwd(FieldBwdArgs b) {
             SCQ_PACE(4);
         }
 #else
+#if NSR_BWD_WQ
+        // ================= recompute forward, keeping rounded activations ====================
+        s8v xd[1] = {cur.xd}, xc[1] = {cur.xc};
+        f4v h[4];
+        s8v hd[2], hk[2], hc[2], hr1[2], hr2[2];
+        f4v logit[1], c1[1], rgb[1];
+        mm_layer32_q<CD, 4, 1>(wq, wl + FW_D1, lane, xd, h);          // queued at the end of the previous tile
+        mm_queue32<2>(wq, wl + FW_D2, lane);
+        if (GOUT) gout_store();            // the previous tile's encoder gradients: after this tile's inputs have been waited for
+#if NSR_BWD_EARLY_NEXT
+        // GOUT has no scatter between the end of the MLP section and the loop edge: loads issued there are waited for at
+        // once (SQ_WAIT_ANY = 51 % of the wave's cycles, profiles/).  The next tile's inputs are requested HERE instead, a
+        // whole MLP section ahead, at the price of 16 registers held through it.
+        if (GOUT && tile + 1 < w_end) nxt = load_tile(tile + 1, fetch_idx(tile + 1));
+#endif
+        mm_pack64<CD, true, NSR_BWD_PKMAX>(h, hd);
+        mm_layer32_q<CD, 1, 2>(wq, wl + FW_D2, lane, hd, logit);
+        mm_queue32<4>(wq, wl + FW_K1, lane);
+        mm_layer32_q<CD, 4, 1>(wq, wl + FW_K1, lane, xc, h);
+        mm_queue32<4>(wq, wl + FW_C1A, lane);
+        mm_pack64<CD, true, NSR_BWD_PKMAX>(h, hk);
+        mm_layer32_q<CD, 4, 1>(wq, wl + FW_C1A, lane, xc, h);
+        mm_queue32<2>(wq, wl + FW_C1B, lane);
+        mm_pack64<CD, true, NSR_BWD_PKMAX>(h, hc);
+        mm_layer32_q<CD, 1, 2>(wq, wl + FW_C1B, lane, hc, c1);
+        mm_queue16<4>(wq16, wl + FW_R1, lane);
+        const s4v c1b = mm_round4<CD, false>(c1[0]);
+        mm_layer16_q<CD, 4>(wq16, c1b, h);
+        mm_queue32<8>(wq, wl + FW_R2, lane);
+        mm_pack64<CD, true, NSR_BWD_PKMAX>(h, hr1);
+        SCQ_PACE(4);
+        mm_layer32_q<CD, 4, 2>(wq, wl + FW_R2, lane, hr1, h);
+        mm_queue32<2>(wq, wl + FW_R3, lane);
+        mm_pack64<CD, true, NSR_BWD_PKMAX>(h, hr2);
+        SCQ_PACE(4);
+        mm_layer32_q<CD, 1, 2>(wq, wl + FW_R3, lane, hr2, rgb);
+        mm_queue16<4>(wq16, wt + BW_R3T, lane);
+
+        // ================= upstream gradients in B-fragment form (row = 4g + e) ===============
+        s4v dyd, dyr, dyk;
+        {
+            float gd[4] = {0.f, 0.f, 0.f, 0.f}, gr[4] = {0.f, 0.f, 0.f, 0.f}, gk[4] = {0.f, 0.f, 0.f, 0.f};
+            if (valid) {
+                if (g == 0) {
+                    // sigma = exp(logit) * density_scale; trunc_exp backward clamps (tcnn_nerf.py:62-66)
+                    const float x = logit[0][0];
+                    gd[0] = cur_gsig * a.density_scale * expf(fminf(fmaxf(x, -15.0f), 15.0f));
+                }
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const int ch = 4 * g + e;
+                    if ((uint32_t)ch < a.C_ch) {
+                        const float gv = cur_grgb[e];
+                        if (ch < 3) {
+                            const float sg = field_sigmoid(rgb[0][e]);
+                            gr[e] = gv * sg * (1.0f - sg);
+                        } else {
+                            gk[e] = gv;
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; e++) { dyd[e] = MM<CD>::cvt(gd[e]); dyr[e] = MM<CD>::cvt(gr[e]); dyk[e] = MM<CD>::cvt(gk[e]); }
+        }
+
+        // ================= color2: 16 -> 64 -> 64 -> 3 =======================================
+        s8v g2[2], g1[2];
+        s4v gc1;
+        {
+            mm_layer16_q<CD, 4>(wq16, dyr, h);
+            mm_queue32<8>(wq, wt + BW_R2T, lane);
+            field_mask_pack<CD>(h, hr2, g2);
+            mm_layer32_q<CD, 4, 2>(wq, wt + BW_R2T, lane, g2, h);
+            mm_queue32<2>(wq, wt + BW_R1T, lane);
+            field_mask_pack<CD>(h, hr1, g1);
+            f4v t1[1];
+            mm_layer32_q<CD, 1, 2>(wq, wt + BW_R1T, lane, g1, t1);
+            mm_queue16<4>(wq16, wt + BW_C1BT, lane);
+            gc1 = mm_round4<CD, false>(t1[0]);
+            // wgrads of r3, r2, r1
+            s4v hr2t[4], hr1t[4], g2t[4], g1t[4];
+            field_tr4<CD>(hr2, ident, hr2t);
+            field_tr4<CD>(g2, ident, g2t);
+            const s4v dyrt[1] = {mm_transpose16<CD>(dyr, ident)};
+            field_wgrad<CD, 1, 4>(w_r3, dyrt, hr2t);
+            SCQ_PACE(4);
+            field_tr4<CD>(hr1, ident, hr1t);
+            field_wgrad<CD, 4, 4>(w_r2, g2t, hr1t);
+            SCQ_PACE(4);
+            field_tr4<CD>(g1, ident, g1t);
+            const s4v c1t[1] = {mm_transpose16<CD>(c1b, ident)};
+            field_wgrad<CD, 4, 1>(w_r1, g1t, c1t);
+            SCQ_PACE(4);
+        }
+        // transposed encoder features (shared by the color1 / class / density wgrads)
+        s4v xct[2], xdt[2];
+        field_tr2<CD>(xc, ident, xct);
+        field_tr2<CD>(xd, ident, xdt);
+
+        // ================= color1: 32 -> 64 -> 16, and class: 32 -> 64 -> nc ==================
+        f4v gxc[2];
+        {
+            s8v gh[2];
+            s4v ght[4], hct[4];
+            mm_layer16_q<CD, 4>(wq16, gc1, h);
+            mm_queue32<4>(wq, wt + BW_C1AT, lane);
+            field_mask_pack<CD>(h, hc, gh);
+            mm_layer32_q<CD, 2, 2>(wq, wt + BW_C1AT, lane, gh, gxc);
+            mm_queue16<4>(wq16, wt + BW_K2T, lane);
+            field_tr4<CD>(hc, ident, hct);
+            const s4v gc1t[1] = {mm_transpose16<CD>(gc1, ident)};
+            field_wgrad<CD, 1, 4>(w_c1b, gc1t, hct);
+            SCQ_PACE(4);
+            field_tr4<CD>(gh, ident, ght);
+            field_wgrad<CD, 4, 2>(w_c1a, ght, xct);
+            SCQ_PACE(4);
+        }
+        {
+            s8v gh[2];
+            s4v ght[4], hkt[4];
+            mm_layer16_q<CD, 4>(wq16, dyk, h);
+            mm_queue32<4>(wq, wt + BW_K1T, lane);
+            field_mask_pack<CD>(h, hk, gh);
+            mm_layer32_q<CD, 2, 2, true>(wq, wt + BW_K1T, lane, gh, gxc);
+            mm_queue16<4>(wq16, wt + BW_D2T, lane);
+            field_tr4<CD>(hk, ident, hkt);
+            const s4v dykt[1] = {mm_transpose16<CD>(dyk, ident)};
+            field_wgrad<CD, 1, 4>(w_k2, dykt, hkt);
+            SCQ_PACE(4);
+            field_tr4<CD>(gh, ident, ght);
+            field_wgrad<CD, 4, 2>(w_k1, ght, xct);
+            SCQ_PACE(4);
+        }
+        // ================= density: 32 -> 64 -> 1 =============================================
+        f4v gxd[2];
+        {
+            s8v gh[2];
+            s4v ght[4], hdt[4];
+            mm_layer16_q<CD, 4>(wq16, dyd, h);
+            mm_queue32<4>(wq, wt + BW_D1T, lane);
+            field_mask_pack<CD>(h, hd, gh);
+            mm_layer32_q<CD, 2, 2>(wq, wt + BW_D1T, lane, gh, gxd);
+            mm_queue32<4>(wq, wl + FW_D1, lane);          // the next tile's first layer
+            field_tr4<CD>(hd, ident, hdt);
+            const s4v dydt[1] = {mm_transpose16<CD>(dyd, ident)};
+            field_wgrad<CD, 1, 4>(w_d2, dydt, hdt);
+            SCQ_PACE(4);
+            field_tr4<CD>(gh, ident, ght);
+            field_wgrad<CD, 4, 2>(w_d1, ght, xdt);
+            SCQ_PACE(4);
+        }
+
+#else
         // ================= recompute forward, keeping rounded activations ====================
         s8v xd[1] = {cur.xd}, xc[1] = {cur.xc};
         f4v h[4];
@@ -685,6 +863,12 @@ k_field_bwd(FieldBwdArgs b) {
         f4v logit[1], c1[1], rgb[1];
         mm_layer32<CD, 4, 1>(wl + FW_D1, lane, xd, h);
         if (GOUT) gout_store();            // the previous tile's encoder gradients: after this tile's inputs have been waited for
+#if NSR_BWD_EARLY_NEXT
+        // GOUT has no scatter between the end of the MLP section and the loop edge: loads issued there are waited for at
+        // once (SQ_WAIT_ANY = 51 % of the wave's cycles, profiles/).  The next tile's inputs are requested HERE instead, a
+        // whole MLP section ahead, at the price of 16 registers held through it.
+        if (GOUT && tile + 1 < w_end) nxt = load_tile(tile + 1, fetch_idx(tile + 1));
+#endif
         mm_pack64<CD, true, NSR_BWD_PKMAX>(h, hd);
         mm_layer32<CD, 1, 2>(wl + FW_D2, lane, hd, logit);
         mm_layer32<CD, 4, 1>(wl + FW_K1, lane, xc, h);
@@ -808,6 +992,7 @@ k_field_bwd(FieldBwdArgs b) {
         }
 
 #endif
+#endif
 
         // ================= table scatter =======================================================
         // gxd[t][2*(i&1)+f] is d L / d feature f of level lvl[i] (t = i >> 1): same lane<->level map
@@ -818,8 +1003,11 @@ k_field_bwd(FieldBwdArgs b) {
         // Next tile's loads go out BEFORE this tile's scatter: the scatter touches LDS only (its records are
         // turned into atomics by the pace points of the next tile), so by the next loop top both these loads
         // and the atomics issued ahead of them (vmcnt retires in order) have had the whole scatter to land.
-        TileIn nxt = cur;
+#if NSR_BWD_EARLY_NEXT
+        if (!GOUT && tile + 1 < w_end) nxt = load_tile(tile + 1, fetch_idx(tile + 1));
+#else
         if (tile + 1 < w_end) nxt = load_tile(tile + 1, fetch_idx(tile + 1));
+#endif
         NSR_TICK(tk3);
         NSR_TACC(3, tk2, tk3);
         if (td || tc) {

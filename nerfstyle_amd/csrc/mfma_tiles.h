@@ -111,10 +111,36 @@ __device__ __forceinline__ void mm_build_frags(short *lds, const float *__restri
     }
 }
 
+// Weight fragments are read from LDS right where they are used.  In a kernel that runs ONE wave per SIMD at the register
+// limit (the field backward) the compiler leaves ~3 instructions between a ds_read and the MFMA that needs it, and nothing
+// else can run while the wave waits: 45 exposed LDS round trips per 16-sample tile, about half of the kernel's cycles.
+// NSR_MM_AHEAD = n keeps n fragment reads in flight ahead of the MFMA stream (a register ring refilled right after the
+// MFMA that consumed the slot, pinned by scheduling barriers); 0 = read at the point of use.
+#ifndef NSR_MM_AHEAD
+#define NSR_MM_AHEAD 0
+#endif
+
 // One layer: acc[m] = sum_u A[m][u] * b[u]  (K = 32 per step)
 template <int CD, int MT, int KP>
 __device__ __forceinline__ void mm_layer32(const short *lds_frags, int lane, const s8v (&b)[KP], f4v (&acc)[MT]) {
     const s8v *F = reinterpret_cast<const s8v *>(lds_frags);
+#if NSR_MM_AHEAD
+    constexpr int N = MT * KP, A = NSR_MM_AHEAD < N ? NSR_MM_AHEAD : N;
+    s8v w[A];
+#pragma unroll
+    for (int i = 0; i < A; i++) w[i] = F[i * 64 + lane];
+    __builtin_amdgcn_sched_barrier(0);
+    f4v a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        const int m = i / KP, u = i % KP;
+        if (u == 0) a = f4v{0.f, 0.f, 0.f, 0.f};
+        a = MM<CD>::k32(w[i % A], b[u], a);
+        if (i + A < N) w[i % A] = F[(i + A) * 64 + lane];
+        if (u == KP - 1) acc[m] = a;
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#else
 #pragma unroll
     for (int m = 0; m < MT; m++) {
         f4v a = {0.f, 0.f, 0.f, 0.f};
@@ -122,26 +148,100 @@ __device__ __forceinline__ void mm_layer32(const short *lds_frags, int lane, con
         for (int u = 0; u < KP; u++) a = MM<CD>::k32(F[(m * KP + u) * 64 + lane], b[u], a);
         acc[m] = a;
     }
+#endif
 }
 // Same, accumulating into acc.
 template <int CD, int MT, int KP>
 __device__ __forceinline__ void mm_layer32_acc(const short *lds_frags, int lane, const s8v (&b)[KP], f4v (&acc)[MT]) {
     const s8v *F = reinterpret_cast<const s8v *>(lds_frags);
+#if NSR_MM_AHEAD
+    constexpr int N = MT * KP, A = NSR_MM_AHEAD < N ? NSR_MM_AHEAD : N;
+    s8v w[A];
+#pragma unroll
+    for (int i = 0; i < A; i++) w[i] = F[i * 64 + lane];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        const int m = i / KP, u = i % KP;
+        acc[m] = MM<CD>::k32(w[i % A], b[u], acc[m]);
+        if (i + A < N) w[i % A] = F[(i + A) * 64 + lane];
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#else
 #pragma unroll
     for (int m = 0; m < MT; m++) {
 #pragma unroll
         for (int u = 0; u < KP; u++) acc[m] = MM<CD>::k32(F[(m * KP + u) * 64 + lane], b[u], acc[m]);
     }
+#endif
 }
 // One layer with a single 16-wide k-block.
 template <int CD, int MT>
 __device__ __forceinline__ void mm_layer16(const short *lds_frags, int lane, s4v b, f4v (&acc)[MT]) {
     const s4v *F = reinterpret_cast<const s4v *>(lds_frags);
+#if NSR_MM_AHEAD
+    s4v w[MT];                       // 8-byte fragments: all of the layer's reads go out together
+#pragma unroll
+    for (int m = 0; m < MT; m++) w[m] = F[m * 64 + lane];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int m = 0; m < MT; m++) {
+        f4v a = {0.f, 0.f, 0.f, 0.f};
+        acc[m] = MM<CD>::k16(w[m], b, a);
+    }
+#else
 #pragma unroll
     for (int m = 0; m < MT; m++) {
         f4v a = {0.f, 0.f, 0.f, 0.f};
         acc[m] = MM<CD>::k16(F[m * 64 + lane], b, a);
     }
+#endif
+}
+
+// ---- layers whose first weight fragments were requested earlier ("queued") ---------------------------------------------
+// mm_queue32 / mm_queue16 issue the first min(N, 4) fragment reads of a layer into a caller-held register queue; the
+// caller places them BEFORE the previous layer's epilogue (conversion / packing VALU work), so that the LDS round trip
+// runs under it.  The *_q layer forms consume the queue and read any further fragments four ahead, as NSR_MM_AHEAD does.
+template <int N>
+__device__ __forceinline__ void mm_queue32(s8v (&wq)[4], const short *lds_frags, int lane) {
+    const s8v *F = reinterpret_cast<const s8v *>(lds_frags);
+#pragma unroll
+    for (int i = 0; i < (N < 4 ? N : 4); i++) wq[i] = F[i * 64 + lane];
+    __builtin_amdgcn_sched_barrier(0);
+}
+template <int N>
+__device__ __forceinline__ void mm_queue16(s4v (&wq)[4], const short *lds_frags, int lane) {
+    const s4v *F = reinterpret_cast<const s4v *>(lds_frags);
+#pragma unroll
+    for (int i = 0; i < (N < 4 ? N : 4); i++) wq[i] = F[i * 64 + lane];
+    __builtin_amdgcn_sched_barrier(0);
+}
+template <int CD, int MT, int KP, bool ACC = false>
+__device__ __forceinline__ void mm_layer32_q(s8v (&wq)[4], const short *lds_frags, int lane, const s8v (&b)[KP], f4v (&acc)[MT]) {
+    const s8v *F = reinterpret_cast<const s8v *>(lds_frags);
+    constexpr int N = MT * KP, A = N < 4 ? N : 4;
+    __builtin_amdgcn_sched_barrier(0);
+    f4v a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        const int m = i / KP, u = i % KP;
+        if (u == 0) a = ACC ? acc[m] : f4v{0.f, 0.f, 0.f, 0.f};
+        a = MM<CD>::k32(wq[i % A], b[u], a);
+        if (i + A < N) wq[i % A] = F[(i + A) * 64 + lane];
+        if (u == KP - 1) acc[m] = a;
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+template <int CD, int MT>
+__device__ __forceinline__ void mm_layer16_q(s4v (&wq)[4], s4v b, f4v (&acc)[MT]) {
+    static_assert(MT <= 4, "queue holds four fragments");
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int m = 0; m < MT; m++) {
+        f4v a = {0.f, 0.f, 0.f, 0.f};
+        acc[m] = MM<CD>::k16(wq[m], b, a);
+    }
+    __builtin_amdgcn_sched_barrier(0);
 }
 
 // 4 accumulator tiles (64 rows) -> two K=32 B fragments, with or without ReLU
