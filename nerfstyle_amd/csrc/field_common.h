@@ -213,7 +213,10 @@ static int field_fill_args(const nsr_field_desc *d, FieldArgs &a, uint32_t M, ui
     const uint32_t ntiles = (M + 15) / 16;
     // >= 8 tiles per wave so the per-block weight-image build amortises; <= 8 blocks per CU
     uint32_t nb = (ntiles + 31) / 32;
-    if (nb > 2048) nb = 2048;
+#ifndef NSR_FIELD_MAX_BLOCKS
+#define NSR_FIELD_MAX_BLOCKS 2048
+#endif
+    if (nb > NSR_FIELD_MAX_BLOCKS) nb = NSR_FIELD_MAX_BLOCKS;
     if (nb == 0) nb = 1;
     nblocks = nb;
     a.tiles_per_block = (ntiles + nb - 1) / nb;

@@ -443,7 +443,10 @@ int nsr_table_scatter_launch(const NsrLevel *levels, const float *bmin, const fl
     a.xyzs = xyzs; a.perm = perm; a.m_dev = m_dev; a.M = M; a.gin = (const float4 *)gin; a.grad_tables = grad_tables;
     for (int i = 0; i < 3; i++) { a.bmin[i] = bmin[i]; a.bsize[i] = bsize[i]; }
     a.td = td; a.tc = tc;
-    const size_t lds = 16 * sizeof(NsrLevel) + (LAT_LAZY_LEVELS < 16 ? (size_t)a.lat_slots * 4 : 0) + (TS_THREADS / 64) * ts_wave_bytes(a.lat_slots);
+#ifndef NSR_ABL_TS_PAD_LDS
+#define NSR_ABL_TS_PAD_LDS 0      /* ablation: extra LDS bytes per workgroup, to lower the occupancy */
+#endif
+    const size_t lds = 16 * sizeof(NsrLevel) + (LAT_LAZY_LEVELS < 16 ? (size_t)a.lat_slots * 4 : 0) + (TS_THREADS / 64) * ts_wave_bytes(a.lat_slots) + NSR_ABL_TS_PAD_LDS;
     static bool attr_set[64] = {};
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -453,10 +456,13 @@ int nsr_table_scatter_launch(const NsrLevel *levels, const float *bmin, const fl
         attr_set[dev & 63] = true;
     }
     if (lds > 65536) return NSR_ERR_UNSUPPORTED;
-    // as many workgroups as fit: LDS-bound (three 4-wave workgroups per CU = 3 waves per SIMD); each wave walks a contiguous run of tiles
-    uint32_t per_cu = (uint32_t)(160u * 1024u / lds);
-    if (per_cu > 8) per_cu = 8;
-    if (per_cu == 0) per_cu = 1;
+    // 16 workgroups per CU (4 096 in all), although only 3-4 are resident at a time: the cost of a run of tiles depends on
+    // how often its samples change block, and with one workgroup per resident slot the slowest run decides the launch
+    // (bench frame, backward pair: 4 per CU 25.5 ms, 6 -> 24.2, 8 -> 23.9, 16 -> 23.55, 32 -> 23.6)
+    uint32_t per_cu = 16;
+#ifdef NSR_ABL_TS_PER_CU
+    per_cu = NSR_ABL_TS_PER_CU;
+#endif
     uint32_t nblocks = 256u * per_cu;
     const uint32_t ntiles = (M + 15) / 16;
     if (nblocks > (ntiles + 3) / 4) nblocks = (ntiles + 3) / 4;
