@@ -229,7 +229,13 @@ constexpr int TS_THREADS = NSR_TS_THREADS;
 #endif
 static size_t ts_wave_bytes(uint32_t lat_slots) { return 256 + (size_t)lat_slots * 16; }
 
+#ifndef NSR_TS_WAVES_PER_EU
+#define NSR_TS_WAVES_PER_EU 0
+#endif
 __global__ void __launch_bounds__(TS_THREADS)
+#if NSR_TS_WAVES_PER_EU
+__attribute__((amdgpu_waves_per_eu(NSR_TS_WAVES_PER_EU, NSR_TS_WAVES_PER_EU)))
+#endif
 k_table_scatter(TableScatterArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     NsrLevel *lds_lv = reinterpret_cast<NsrLevel *>(smem);
