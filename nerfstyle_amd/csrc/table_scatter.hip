@@ -32,6 +32,19 @@ __device__ __forceinline__ bool seq_nonzero(const float4 &v) {
     return ((__float_as_uint(v.x) | __float_as_uint(v.y) | __float_as_uint(v.z) | __float_as_uint(v.w)) << 1) != 0u;
 }
 
+// nsr_grid_row for style 0 with the cheap cases taken out (the level is wave-uniform here): a power-of-two table is
+// masked, a dense level needs neither 32-bit multiplies (index < 2^19) nor the modulo (index < (res + 1)^3 <= size).
+__device__ __forceinline__ uint32_t lat_row(const NsrLevel &lv, uint32_t x, uint32_t y, uint32_t z) {
+    if (lv.use_hash) {
+        const uint32_t index = x ^ (y * 2654435761u) ^ (z * 805459861u);
+        if ((lv.size & (lv.size - 1u)) == 0u) return index & (lv.size - 1u);
+        const uint32_t t = __umulhi(lv.magic, index);
+        const uint32_t q = (t + ((index - t) >> lv.sh1)) >> lv.sh2;
+        return index - q * lv.size;
+    }
+    return __umul24(x, lv.mul[0]) + __umul24(y, lv.mul[1]) + __umul24(z, lv.mul[2]);
+}
+
 struct LatGeom {
     uint16_t base[16];      // first slot of the level's lattice
     uint8_t S[16];          // corners per axis
@@ -83,8 +96,12 @@ __device__ __forceinline__ void lat_flush_level(float4 *__restrict__ lat4, uint3
         const unsigned long long m = __ballot(nz);
         if (m == 0ull) continue;                                          // wave-uniform: nothing touched in these slots
         if (nz) {
-            const int z = k / (S * S), r = k - z * (S * S), y = r / S, x = r - y * S;
-            rows[lane] = lv.offset + nsr_grid_row(lv, b0 + (uint32_t)x, b1 + (uint32_t)y, b2 + (uint32_t)z, 0u);
+            // k < 256: the divisions by S*S and S are 24-bit multiplies by 16-bit reciprocals (exact on this range); a 32-bit
+            // integer multiply costs four issue slots on this machine and the scatter is issue bound
+            constexpr uint32_t MZ = (65536u + S * S - 1u) / (S * S), MY = (65536u + S - 1u) / S;
+            const uint32_t z = __umul24((uint32_t)k, MZ) >> 16, r = (uint32_t)k - __umul24(z, (uint32_t)(S * S));
+            const uint32_t y = __umul24(r, MY) >> 16, x = r - __umul24(y, (uint32_t)S);
+            rows[lane] = lv.offset + lat_row(lv, b0 + x, b1 + y, b2 + z);
         }
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -372,8 +389,8 @@ k_table_scatter(TableScatterArgs a) {
                 // fp32 rounding put the cell one past the lattice (u * res of a sample at the very end of its block can
                 // round up across a cell boundary that the block's real extent stops short of): this sample's two corners
                 // go straight to the table, exactly; the (clamped) lattice slots get nothing
-                const uint32_t rowA = lv.offset + nsr_grid_row(lv, c0, c1 + (uint32_t)py, c2 + (uint32_t)pz, 0u);
-                const uint32_t rowB = lv.offset + nsr_grid_row(lv, c0 + 1u, c1 + (uint32_t)py, c2 + (uint32_t)pz, 0u);
+                const uint32_t rowA = lv.offset + lat_row(lv, c0, c1 + (uint32_t)py, c2 + (uint32_t)pz);
+                const uint32_t rowB = lv.offset + lat_row(lv, c0 + 1u, c1 + (uint32_t)py, c2 + (uint32_t)pz);
                 const float ga[4] = {gr.x, gr.y, gr.z, gr.w};
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
@@ -385,7 +402,7 @@ k_table_scatter(TableScatterArgs a) {
                 wA = 0.0f;
                 wB = 0.0f;
             }
-            float4 *const slot = mylat + ((r2 * S + r1) * S + r0);
+            float4 *const slot = mylat + (__umul24(__umul24(r2, S) + r1, S) + r0);
 #if NSR_TS_LDS_ATOMIC
             // fire-and-forget LDS float adds: no read -> fma -> write round trip to wait for (the lattice is private to the wave
             // and the 64 lanes of a step touch 128 different slots, so nothing conflicts)
