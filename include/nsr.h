@@ -242,7 +242,9 @@ int nsr_field_backward(const nsr_field_desc *desc, const void *tables, const flo
                        const float *grad_rgbs, float *grad_tables, float *grad_mlp,
                        int train_density_table, int train_color_table, const void *feats,
                        const uint32_t *perm, void *workspace, nsr_stream_t stream);
-/* perm != NULL (nsr_sample_order): the MLP backward writes every sample's encoder-output gradient (256 B) to
+/* feats given together with perm must come from nsr_field_forward called with the SAME perm (they are tile-major in
+ * perm's order; the first kernel below walks that order).
+ * perm != NULL (nsr_sample_order): the MLP backward writes every sample's encoder-output gradient (256 B) to
  * `workspace` and a second, high-occupancy kernel accumulates the table gradient walking the samples in perm's
  * spatial order (LDS lattices, one merged atomic record per touched corner; csrc/table_scatter.hip).  Pays on dense
  * (full-frame) batches; results equal the perm == NULL call up to fp32 summation order.

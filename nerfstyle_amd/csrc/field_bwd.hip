@@ -468,9 +468,12 @@ k_field_bwd(FieldBwdArgs b) {
         float gsig;        // grad_sigmas[m] (used by the g == 0 lanes)
         float grgb[4];     // grad_rgbs[m, 4g .. 4g+3]
     };
-    // position `16 * tile + s` of the walk -> index into the sample buffers (0 for lanes past the count)
+    // position `16 * tile + s` of the walk -> index into the sample buffers (a valid one for lanes past the count).  With a
+    // permutation (GOUT only: the forward walked the same order, its saved features are tile-major in it) this is a LOAD:
+    // the entry of tile t + 2 is requested while tile t runs, so that tile t + 1's loads never wait for their index.
     auto fetch_idx = [&](uint32_t tile) -> uint32_t {
         const uint32_t m = tile * 16 + s;
+        if (GOUT && NSR_BWD_EARLY_NEXT && a.perm) return a.perm[min(m, Mc - 1u)];
         return m < Mc ? m : 0u;
     };
     auto load_tile = [&](uint32_t tile, uint32_t buf_idx) {
@@ -501,7 +504,14 @@ k_field_bwd(FieldBwdArgs b) {
     const uint32_t wchunk = (t_end > t_begin ? (t_end - t_begin + BWD_THREADS / 64 - 1) / (BWD_THREADS / 64) : 0u);
     const uint32_t w_begin = min(t_begin + wave * wchunk, t_end), w_end = min(w_begin + wchunk, t_end);
     TileIn cur;
-    if (w_begin < w_end) cur = load_tile(w_begin, fetch_idx(w_begin));
+    uint32_t idx_cur = 0, idx_next = 0;          // buffer index of this lane's sample in the current / next tile
+    if (w_begin < w_end) {
+        idx_cur = fetch_idx(w_begin);
+        cur = load_tile(w_begin, idx_cur);
+#if NSR_BWD_EARLY_NEXT
+        idx_next = w_begin + 1 < w_end ? fetch_idx(w_begin + 1) : idx_cur;
+#endif
+    }
     // GOUT: one tile's per-level encoder gradients, 4 x 16 bytes per lane = 256 contiguous bytes per sample ([16][4] floats)
     float4 gout_v[4];
     uint32_t gout_m = 0;
@@ -550,7 +560,7 @@ k_field_bwd(FieldBwdArgs b) {
         // MFMA that reads cur.xc).  The loads of `cur` are a whole tile old at this point.
         if (GOUT)
             asm volatile("" :: "v"(cur.x0), "v"(cur.x1), "v"(cur.x2), "v"(cur.gsig), "v"(cur.grgb[0]), "v"(cur.grgb[1]),
-                         "v"(cur.grgb[2]), "v"(cur.grgb[3]), "v"(cur.xd), "v"(cur.xc));
+                         "v"(cur.grgb[2]), "v"(cur.grgb[3]), "v"(cur.xd), "v"(cur.xc), "v"(idx_next));
 #endif
         const float u0 = valid ? field_unit(cur.x0, a.bmin[0], a.bsize[0]) : 0.f;
         const float u1 = valid ? field_unit(cur.x1, a.bmin[1], a.bsize[1]) : 0.f;
@@ -566,9 +576,11 @@ k_field_bwd(FieldBwdArgs b) {
 
         // paced drain of the previous tile's records: SCQ_PACE(n) issues <= n atomic wave-instructions
 #define SCQ_PACE(n) do { if (!GOUT) scq_pace(q, gt1, lane, td, tc, (n), false); } while (0)
+#if NSR_BWD_EARLY_NEXT
         // (value-initialised, NOT a copy of cur: copying cur's not-yet-used members here would wait for their loads, and
         // -- one in-order vmcnt -- for the gradient stores issued in between)
         TileIn nxt{};
+#endif
 #if NSR_BWD_NET_ORDER
         // ================= one net at a time: forward recompute -> dgrad -> wgrad, then its activations are dead ===========
         // (The straight order -- all four forwards, then all backwards -- keeps hd, hk, hc, hr1, hr2 alive together: 40
@@ -715,7 +727,11 @@ k_field_bwd(FieldBwdArgs b) {
         // GOUT has no scatter between the end of the MLP section and the loop edge: loads issued there are waited for at
         // once (SQ_WAIT_ANY = 51 % of the wave's cycles, profiles/).  The next tile's inputs are requested HERE instead, a
         // whole MLP section ahead, at the price of 16 registers held through it.
-        if (GOUT && tile + 1 < w_end) nxt = load_tile(tile + 1, fetch_idx(tile + 1));
+        uint32_t idx_nn = idx_next;
+        if (GOUT && tile + 1 < w_end) {
+            nxt = load_tile(tile + 1, idx_next);
+            if (tile + 2 < w_end) idx_nn = fetch_idx(tile + 2);
+        }
 #endif
         mm_pack64<CD, true, NSR_BWD_PKMAX>(h, hd);
         mm_layer32_q<CD, 1, 2>(wq, wl + FW_D2, lane, hd, logit);
@@ -867,7 +883,11 @@ k_field_bwd(FieldBwdArgs b) {
         // GOUT has no scatter between the end of the MLP section and the loop edge: loads issued there are waited for at
         // once (SQ_WAIT_ANY = 51 % of the wave's cycles, profiles/).  The next tile's inputs are requested HERE instead, a
         // whole MLP section ahead, at the price of 16 registers held through it.
-        if (GOUT && tile + 1 < w_end) nxt = load_tile(tile + 1, fetch_idx(tile + 1));
+        uint32_t idx_nn = idx_next;
+        if (GOUT && tile + 1 < w_end) {
+            nxt = load_tile(tile + 1, idx_next);
+            if (tile + 2 < w_end) idx_nn = fetch_idx(tile + 2);
+        }
 #endif
         mm_pack64<CD, true, NSR_BWD_PKMAX>(h, hd);
         mm_layer32<CD, 1, 2>(wl + FW_D2, lane, hd, logit);
@@ -1006,6 +1026,8 @@ k_field_bwd(FieldBwdArgs b) {
 #if NSR_BWD_EARLY_NEXT
         if (!GOUT && tile + 1 < w_end) nxt = load_tile(tile + 1, fetch_idx(tile + 1));
 #else
+        // (the fused tracker unit: exactly this shape -- moving the declaration or the loads costs it several ms)
+        TileIn nxt = cur;
         if (tile + 1 < w_end) nxt = load_tile(tile + 1, fetch_idx(tile + 1));
 #endif
         NSR_TICK(tk3);
@@ -1022,7 +1044,7 @@ k_field_bwd(FieldBwdArgs b) {
                 // would be waited for -- one in-order vmcnt -- together with the next tile's loads at the loop top
 #pragma unroll
                 for (int i = 0; i < 4; i++) gout_v[i] = sg[i];
-                gout_m = m;
+                gout_m = NSR_BWD_EARLY_NEXT ? idx_cur : m;        // (without the early loads the walk is in buffer order)
                 gout_valid = valid;
             }
             else field_scatter_seq(seq, lds_lv, seqG, q, gt1, live ? u0 : 0.f, live ? u1 : 0.f, live ? u2 : 0.f, sg, lane, td, tc);
@@ -1030,6 +1052,9 @@ k_field_bwd(FieldBwdArgs b) {
         NSR_TICK(tk4);
         NSR_TACC(2, tk3, tk4);
         cur = nxt;
+#if NSR_BWD_EARLY_NEXT
+        if (GOUT) { idx_cur = idx_next; idx_next = idx_nn; }
+#endif
     }
 #ifdef NSR_ABL_STATS
     for (int i = 0; i < 4; i++) NSR_STAT_ALWAYS(4 + i, tacc[i]);
@@ -1112,6 +1137,9 @@ int nsr_field_bwd_launch_gout(const FieldBwdArgs &b, int table_dtype, int comput
 
 #ifdef NSR_BWD_TU_GOUT
 int nsr_field_bwd_launch_gout(const FieldBwdArgs &b, int table_dtype, int compute_dtype, bool feats, dim3 grid, hipStream_t s) {
+#if !NSR_BWD_EARLY_NEXT
+    if (b.f.perm != nullptr) return NSR_ERR_UNSUPPORTED;      // an ablation build without the index prefetch cannot walk a permutation
+#endif
     return field_bwd_launch_variant<true>(b, table_dtype, compute_dtype, feats, grid, s);
 }
 #else
@@ -1141,9 +1169,12 @@ int nsr_field_backward(const nsr_field_desc *desc, const void *tables, const flo
     if (nblocks > 256) nblocks = 256;
     b.f.tiles_per_block = (ntiles + nblocks - 1) / nblocks;
     b.f.tables = tables; b.f.params = mlp_params; b.f.xyzs = xyzs; b.f.m_dev = m_dev; b.f.sigmas = nullptr; b.f.rgbs = nullptr;
-    b.f.feats = const_cast<void *>(feats);
-    b.f.perm = nullptr;                         // this kernel always walks in buffer order; `perm` orders the table scatter
     const bool gout = perm != nullptr && (train_density_table || train_color_table);
+    // `feats` given together with `perm` were written by nsr_field_forward in perm's order (tile-major): the gradients-out
+    // kernel walks the same order; the fused tracker kernel walks the buffers and cannot use them (it re-gathers)
+    if (perm != nullptr && !gout) feats = nullptr;
+    b.f.feats = const_cast<void *>(feats);
+    b.f.perm = (gout && feats != nullptr) ? perm : nullptr;      // (the gradients-out unit is built with NSR_BWD_EARLY_NEXT)
     b.gout = nullptr;
     if (gout) {
         if (workspace == nullptr || ((uintptr_t)workspace & 15u)) return NSR_ERR_INVALID_ARG;

@@ -89,8 +89,8 @@ class _field(Function):
             feats = torch.empty(((M + 15) // 16) * 512, dtype=torch.int32, device=dev)
         with profiling.timed('field_fwd_sigma' if sigma_only else 'field_fwd'):
             L.check(L.lib().nsr_field_forward(ctypes.byref(desc), L.p(tables), L.p(model._mlp_flat()),
-                                              L.p(xyzs), M, L.p(m_dev), L.p(sigmas), L.p(rgbs), L.p(feats), None,
-                                              L.stream()),
+                                              L.p(xyzs), M, L.p(m_dev), L.p(sigmas), L.p(rgbs), L.p(feats),
+                                              L.p(perm) if feats is not None else None, L.stream()),
                     'field_forward')
         ctx.model = model
         ctx.m_dev = m_dev
@@ -141,6 +141,7 @@ class _field(Function):
                     L.stream())
             st = call(perm, ws)
             if st == -2 and perm is not None:
+                feats = None             # saved in the permutation's order: useless to a kernel that walks the buffers
                 # NSR_ERR_UNSUPPORTED: a grid finer than the spatial scatter's LDS lattices hold (finest resolution above
                 # ~5 cells per 1/1024 block) -- nothing was launched; the fused run-tracker backward takes over
                 model._spatial_scatter_unsupported = True
