@@ -60,7 +60,7 @@ def parse():
     ap.add_argument('--fp32-loss', action='store_true', help='style stage: VGG + style loss in fp32 instead of autocast')
     ap.add_argument('--no-occ-update', action='store_true', help='leave the periodic occupancy update out of the step')
     ap.add_argument('--sort-samples', choices=['auto', 'on', 'off'], default='auto',
-                    help="spatially ordered table scatter in the backward (nsr_sample_order): 'auto' = dense batches (>= 200 000 rays) only")
+                    help="spatially ordered table scatter in the backward (nsr_sample_order): 'auto' = batches of >= 140 000 rays, dense pixel sets from 16 384")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--graph', action='store_true',
                     help='replay the render+loss+backward part of the step as one captured hipGraph (small-batch series)')
