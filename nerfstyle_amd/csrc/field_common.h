@@ -100,8 +100,13 @@ template <> struct RowLd<_Float16> {
     // conversions per level disappear from a kernel that is VALU-issue-bound half of the time
     static __device__ __forceinline__ void accumulate(const _Float16 *t, const uint32_t (&rows)[8], const float (&w)[8], float4 &acc) {
         uint2 v[8];
+#ifdef NSR_ABL_FWD_HALFGATHER
+#pragma unroll
+        for (int idx = 0; idx < 8; idx += 2) v[idx] = v[idx + 1] = reinterpret_cast<const uint2 *>(t)[rows[idx]];
+#else
 #pragma unroll
         for (int idx = 0; idx < 8; idx++) v[idx] = reinterpret_cast<const uint2 *>(t)[rows[idx]];
+#endif
 #pragma unroll
         for (int idx = 0; idx < 8; idx++) {
             asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,0]" : "+v"(acc.x) : "v"(w[idx]), "v"(v[idx].x));
