@@ -5,13 +5,14 @@
 // samples in the permutation's spatial order and accumulates the table gradient.  Why two kernels: the MLP backward
 // needs one wave per SIMD (240 weight-gradient accumulators per lane), and the scatter is a chain of dependent LDS
 // round trips and atomics that one wave per SIMD cannot hide (measured fused: MLP 13.8 ms + scatter 32 ms on the bench
-// frame).  Here a wave needs ~64 registers and 11.5 KB of LDS, so ten of them share a CU.
+// frame).  Here a wave needs 136 registers and ~9.5 KB of LDS, so three of them share a SIMD.
 //
 // Lattice accumulator.  The order's key is the sample's BLOCK: its encoder input quantised to 10 bits per axis (a 4^3
 // group of finest-level cells for the reference's 16-level grid).  Consecutive samples -- of MANY rays -- share a block,
 // and a block touches only a handful of cells on every level: at most ceil(res_l / 1024) + 1 per axis.  So the wave
-// keeps, per level, a small LATTICE of corner gradients in LDS anchored at the cell of the block's origin (5^3 corners
-// on the two finest levels, 4^3 on the next two, 3^3 below: 702 float4 = 11 KB per wave).  Lane = (level l = lane >> 2,
+// keeps, per level, a small LATTICE of corner gradients in LDS anchored at the cell of the block's origin (ceil(res / 1024)
+// + 2 corners per axis: for the reference's LLFF grid -- 16 levels, resolutions 16 .. 2047 -- 4^3 on the three finest levels
+// and 3^3 below, 543 float4 = 8.5 KB per wave; grids up to 6^3 per level and 1024 slots in all are accepted).  Lane = (level l = lane >> 2,
 // y/z corner pair p = lane & 3) walks the samples in order and adds its two x corners' contributions with a plain LDS
 // read-modify-write: within a step the 64 lanes touch 128 different slots and steps are sequential, so no atomics are
 // needed; the lattice is addressed by cell coordinates, so nothing is hashed per sample.  When the walk enters a new
