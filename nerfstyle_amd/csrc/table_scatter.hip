@@ -49,6 +49,7 @@ __device__ __forceinline__ uint32_t lat_row(const NsrLevel &lv, uint32_t x, uint
 struct LatGeom {
     uint16_t base[16];      // first slot of the level's lattice
     uint8_t S[16];          // corners per axis
+    uint8_t shift[16];      // the level's lattice is anchored at the origin of the 2^shift-block group the walk is in
 };
 constexpr int LAT_MAX_SLOTS = 1024;                  // float4 slots per wave (16 KB)
 constexpr int LAT_KEY_BITS = 10;                     // must match nsr_sample_order's quantisation
@@ -57,16 +58,30 @@ struct LatState {
     uint32_t b0, b1, b2;     // anchor cell of this lane's level (LAT_NONE: nothing accumulated yet)
 };
 
-// Host: lattice geometry for the 1/1024 blocks of the sample order.  A block spans e = res / 1024 cells of a level:
-// it touches at most floor(e) + 2 cells per axis (exactly e when the level's cells tile the block), one more corner.
+// corners per axis of a lattice that covers every cell a group of 2^shift blocks (each 1/1024 wide) can touch on a level:
+// the group spans e = res * 2^shift / 1024 cells, i.e. at most floor(e) + 2 of them (exactly e when the cells tile it)
+static uint32_t lat_corners(uint32_t res, uint32_t shift) {
+    const uint64_t span = (uint64_t)res << shift, blocks = 1u << LAT_KEY_BITS;
+    const uint32_t cells = (span % blocks == 0) ? (uint32_t)(span / blocks) : (uint32_t)(span / blocks) + 2u;
+    return cells + 1u;
+}
+
+// Host: lattice geometry.  The walk is in Morton order of the blocks, so the 8 (64, ...) blocks of an aligned group follow
+// one another; a level whose cells are larger than a block is anchored at the GROUP's origin as long as that costs no
+// lattice slots (a group narrower than a cell still touches at most 2 cells per axis: 3^3 corners) -- its lattice then
+// survives the block changes inside the group and is flushed that much less often (bench frame, backward pair: 23.5 ->
+// 22.3 ms).  Levels finer than that keep the block as their anchor: paying a 4^3 lattice for a group of two on the levels
+// with cells of 1 - 2 blocks was measured and lost (22.7 ms: more slots to scan per flush, more LDS).
 static bool lat_geometry(const NsrLevel *lv, LatGeom &g) {
     uint32_t total = 0;
     for (int l = 0; l < 16; l++) {
-        const uint32_t res = lv[l].resolution, blocks = 1u << LAT_KEY_BITS;
-        const uint32_t cells = (res % blocks == 0) ? res / blocks : res / blocks + 2;
-        const uint32_t S = cells + 1;
-        if (S > 6) return false;
+        const uint32_t res = lv[l].resolution;
+        uint32_t shift = 0, S = lat_corners(res, 0);
+        while (shift < (uint32_t)LAT_KEY_BITS && lat_corners(res, shift + 1) <= (S > 3u ? S : 3u)) shift++;   // free
+        S = lat_corners(res, shift) > S ? lat_corners(res, shift) : S;
+        if (S < 2u || S > 6u) return false;
         g.S[l] = (uint8_t)S;
+        g.shift[l] = (uint8_t)shift;
         g.base[l] = (uint16_t)total;
         total += S * S * S;
     }
@@ -125,7 +140,7 @@ __device__ __forceinline__ void lat_flush_level(float4 *__restrict__ lat4, uint3
     }
 }
 
-// The geometry of level fl comes from the LDS copy of the level table (pad_ = S | base << 8): a read from the
+// The geometry of level fl comes from the LDS copy of the level table (pad_ = S | shift << 4 | base << 8): a read from the
 // kernel-argument segment here would be a vector-memory load, and waiting for it means waiting for every atomic in flight.
 __device__ __forceinline__ void lat_flush_dispatch(float4 *__restrict__ lat, int fl, const LatState &st,
                                                    const NsrLevel *__restrict__ lds_lv, float *__restrict__ gt, int lane, bool td, bool tc) {
@@ -140,7 +155,7 @@ __device__ __forceinline__ void lat_flush_dispatch(float4 *__restrict__ lat, int
     NSR_STAT(1, 1);
     float4 *lf = lat + (flv.pad_ >> 8);
     uint32_t *rows = reinterpret_cast<uint32_t *>(lat) - 64;                  // 64-entry row scratch in front of the lattices
-    switch (flv.pad_ & 0xFFu) {
+    switch (flv.pad_ & 0xFu) {
     case 3: lat_flush_level<3>(lf, rows, o0, o1, o2, flv, gt, lane, td, tc); break;
     case 4: lat_flush_level<4>(lf, rows, o0, o1, o2, flv, gt, lane, td, tc); break;
     case 5: lat_flush_level<5>(lf, rows, o0, o1, o2, flv, gt, lane, td, tc); break;
@@ -148,71 +163,6 @@ __device__ __forceinline__ void lat_flush_dispatch(float4 *__restrict__ lat, int
     }
 }
 
-
-#ifndef NSR_TS_LAZY_LEVELS
-#define NSR_TS_LAZY_LEVELS 16          /* levels below this keep their lattice across blocks; 16 = all lazy (no block flush) */
-#endif
-constexpr int LAT_LAZY_LEVELS = NSR_TS_LAZY_LEVELS;
-
-// Flushes the lattices of levels >= LAT_LAZY_LEVELS, all anchored at block `key`, in ONE pass over their slots
-// [first, end): no per-level dispatch, the reads of four 64-slot trips are in flight together, the anchor of a slot's
-// level is recomputed from the block key (the same nsr_grid_locate the accumulating lanes used).
-__device__ __forceinline__ void lat_flush_block(float4 *__restrict__ lat, const uint32_t *__restrict__ slot_info, uint32_t key,
-                                                uint32_t first, uint32_t end, const NsrLevel *__restrict__ lds_lv,
-                                                float *__restrict__ gt, int lane, bool td, bool tc) {
-    const float rk = 1.0f / (float)(1 << LAT_KEY_BITS);
-    const float o0 = (float)(key & ((1u << LAT_KEY_BITS) - 1u)) * rk, o1 = (float)((key >> LAT_KEY_BITS) & ((1u << LAT_KEY_BITS) - 1u)) * rk,
-                o2 = (float)(key >> (2 * LAT_KEY_BITS)) * rk;
-    uint32_t *rows = reinterpret_cast<uint32_t *>(lat) - 64;
-    const float *lf = reinterpret_cast<const float *>(lat);
-    const int t = lane >> 2, i = lane & 3;
-    const bool on = (i < 2) ? td : tc;
-#pragma unroll 1
-    for (uint32_t c0 = first; c0 < end; c0 += 256) {
-        float4 v[4];
-        uint32_t info[4];
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const uint32_t k = c0 + 64 * j + (uint32_t)lane;
-            v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-            info[j] = 0u;
-            if (k < end) { v[j] = lat[k]; info[j] = slot_info[k]; }
-        }
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const uint32_t k0 = c0 + 64 * j, k = k0 + (uint32_t)lane;
-            if (k0 >= end) break;                                              // wave-uniform
-            const bool nz = seq_nonzero(v[j]);
-            const unsigned long long m = __ballot(nz);
-            if (m == 0ull) continue;                                           // wave-uniform: nothing touched in these slots
-            if (nz) {
-                const NsrLevel lv = lds_lv[info[j] & 15u];
-                float ff;
-                uint32_t a0, a1, a2;
-                nsr_grid_locate(o0, lv.resolution, 1, ff, a0);
-                nsr_grid_locate(o1, lv.resolution, 1, ff, a1);
-                nsr_grid_locate(o2, lv.resolution, 1, ff, a2);
-                rows[lane] = lv.offset + nsr_grid_row(lv, a0 + ((info[j] >> 4) & 15u), a1 + ((info[j] >> 8) & 15u), a2 + ((info[j] >> 12) & 15u), 0u);
-            }
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                if (((m >> (16 * q)) & 0xFFFFull) == 0ull) continue;          // wave-uniform
-                if ((m >> (16 * q + t)) & 1ull) {
-                    const float val = lf[(k0 + 16 * q + t) * 4 + i];
-                    const uint32_t row = rows[16 * q + t];
-#ifndef NSR_ABL_NO_ATOMIC
-                    if (on) atomicAdd(gt + (size_t)row * 4 + i, val);
-#else
-                    if (on && row == 0xFFFFFFFFu) gt[i] = val;
-#endif
-                }
-            }
-            __builtin_amdgcn_wave_barrier();
-            if (nz) lat[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-    }
-}
 
 struct TableScatterArgs {
     const float *xyzs;
@@ -224,7 +174,7 @@ struct TableScatterArgs {
     float bmin[3], bsize[3];
     int td, tc;
     uint32_t lat_slots;           // float4 slots per wave (multiple of 64)
-    NsrLevel lv[16];              // pad_ = S | base << 8
+    NsrLevel lv[16];              // pad_ = S | shift << 4 | base << 8
 };
 
 #ifndef NSR_TS_THREADS
@@ -259,19 +209,7 @@ k_table_scatter(TableScatterArgs a) {
     NsrLevel *lds_lv = reinterpret_cast<NsrLevel *>(smem);
     if (threadIdx.x < 16) lds_lv[threadIdx.x] = a.lv[threadIdx.x];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t *const slot_info = reinterpret_cast<uint32_t *>(smem + 16 * sizeof(NsrLevel));
-    const size_t slot_bytes = LAT_LAZY_LEVELS < 16 ? (size_t)a.lat_slots * 4 : 0;
-    if (LAT_LAZY_LEVELS < 16) {
-        // slot -> level | x << 4 | y << 8 | z << 12 (corner offset inside the level's lattice)
-        for (int l2 = 0; l2 < 16; l2++) {
-            const uint32_t S2 = a.lv[l2].pad_ & 0xFFu, base2 = a.lv[l2].pad_ >> 8, n2 = S2 * S2 * S2;
-            for (uint32_t k = threadIdx.x; k < n2; k += TS_THREADS) {
-                const uint32_t z = k / (S2 * S2), r = k - z * S2 * S2, y = r / S2, x = r - y * S2;
-                slot_info[base2 + k] = (uint32_t)l2 | (x << 4) | (y << 8) | (z << 12);
-            }
-        }
-    }
-    char *base = smem + 16 * sizeof(NsrLevel) + slot_bytes + (size_t)wave * (256 + (size_t)a.lat_slots * 16);
+    char *base = smem + 16 * sizeof(NsrLevel) + (size_t)wave * (256 + (size_t)a.lat_slots * 16);
     float4 *lat = reinterpret_cast<float4 *>(base + 256);               // the 64-entry row scratch sits in front of it
     for (uint32_t k = lane; k < a.lat_slots; k += 64) lat[k] = make_float4(0.f, 0.f, 0.f, 0.f);
     __syncthreads();
@@ -286,7 +224,7 @@ k_table_scatter(TableScatterArgs a) {
     const int s = lane & 15;
     const int l = lane >> 2, py = lane & 1, pz = (lane >> 1) & 1;
     const NsrLevel lv = lds_lv[l];
-    const uint32_t S = lv.pad_ & 0xFFu;
+    const uint32_t S = lv.pad_ & 0xFu, ashift = (lv.pad_ >> 4) & 0xFu;
     float4 *const mylat = lat + (lv.pad_ >> 8) + ((uint32_t)pz * S + (uint32_t)py) * S;
     const bool td = a.td != 0, tc = a.tc != 0;
     float *const gt = a.grad_tables;
@@ -294,8 +232,6 @@ k_table_scatter(TableScatterArgs a) {
     LatState st;
     st.b0 = st.b1 = st.b2 = LAT_NONE;
     uint32_t cur_key = LAT_NONE;
-    const uint32_t flush_first = LAT_LAZY_LEVELS < 16 ? (lds_lv[LAT_LAZY_LEVELS < 16 ? LAT_LAZY_LEVELS : 15].pad_ >> 8) : 0u;
-    const uint32_t flush_end = (lds_lv[15].pad_ >> 8) + (lds_lv[15].pad_ & 0xFFu) * (lds_lv[15].pad_ & 0xFFu) * (lds_lv[15].pad_ & 0xFFu);
 
     // position 16 * tile + s of the order -> buffer index; lanes past the count read the last valid entry (masked later)
     auto fetch_idx = [&](uint32_t tile) -> uint32_t { return a.perm[min(tile * 16 + (uint32_t)s, Mc - 1u)]; };
@@ -352,18 +288,19 @@ k_table_scatter(TableScatterArgs a) {
             const uint32_t key = (uint32_t)__builtin_amdgcn_readlane((int)bkey, step);
             if (key != cur_key) {
                 // ---- the walk enters another block: re-anchor every level at the cell of the block's origin ----
-                if (LAT_LAZY_LEVELS < 16 && cur_key != LAT_NONE)
-                    lat_flush_block(lat, slot_info, cur_key, flush_first, flush_end, lds_lv, gt, lane, td, tc);
                 cur_key = key;
-                const float o0 = (float)(key & ((1u << LAT_KEY_BITS) - 1u)) * rk, o1 = (float)((key >> LAT_KEY_BITS) & ((1u << LAT_KEY_BITS) - 1u)) * rk,
-                            o2 = (float)(key >> (2 * LAT_KEY_BITS)) * rk;
+                // origin of the group of 2^ashift blocks (this lane's level) the block belongs to
+                const uint32_t kq0 = key & ((1u << LAT_KEY_BITS) - 1u), kq1 = (key >> LAT_KEY_BITS) & ((1u << LAT_KEY_BITS) - 1u),
+                               kq2 = key >> (2 * LAT_KEY_BITS);
+                const float o0 = (float)((kq0 >> ashift) << ashift) * rk, o1 = (float)((kq1 >> ashift) << ashift) * rk,
+                            o2 = (float)((kq2 >> ashift) << ashift) * rk;
                 float ff;
                 uint32_t n0, n1, n2;
                 nsr_grid_locate(o0, lv.resolution, 1, ff, n0);
                 nsr_grid_locate(o1, lv.resolution, 1, ff, n1);
                 nsr_grid_locate(o2, lv.resolution, 1, ff, n2);
                 const bool chg = (n0 != st.b0) | (n1 != st.b1) | (n2 != st.b2);
-                unsigned long long mm = __ballot(chg && l < LAT_LAZY_LEVELS);
+                unsigned long long mm = __ballot(chg);
                 while (mm) {
                     const int fl = (int)(__builtin_ctzll(mm) >> 2);
                     mm &= ~(0xFull << (fl * 4));
@@ -442,9 +379,8 @@ k_table_scatter(TableScatterArgs a) {
     }
     // every level's lattice leaves
     __builtin_amdgcn_wave_barrier();
-    if (LAT_LAZY_LEVELS < 16 && cur_key != LAT_NONE) lat_flush_block(lat, slot_info, cur_key, flush_first, flush_end, lds_lv, gt, lane, td, tc);
 #pragma unroll 1
-    for (int fl = 0; fl < LAT_LAZY_LEVELS; fl++) lat_flush_dispatch(lat, fl, st, lds_lv, gt, lane, td, tc);
+    for (int fl = 0; fl < 16; fl++) lat_flush_dispatch(lat, fl, st, lds_lv, gt, lane, td, tc);
 }
 
 bool nsr_table_scatter_supported(const NsrLevel *lv) {
@@ -460,7 +396,7 @@ int nsr_table_scatter_launch(const NsrLevel *levels, const float *bmin, const fl
     uint32_t total = 0;
     for (int l = 0; l < 16; l++) {
         a.lv[l] = levels[l];
-        a.lv[l].pad_ = (uint32_t)g.S[l] | ((uint32_t)g.base[l] << 8);
+        a.lv[l].pad_ = (uint32_t)g.S[l] | ((uint32_t)g.shift[l] << 4) | ((uint32_t)g.base[l] << 8);
         total = g.base[l] + (uint32_t)g.S[l] * g.S[l] * g.S[l];
     }
     a.lat_slots = (total + 63u) & ~63u;
@@ -470,7 +406,7 @@ int nsr_table_scatter_launch(const NsrLevel *levels, const float *bmin, const fl
 #ifndef NSR_ABL_TS_PAD_LDS
 #define NSR_ABL_TS_PAD_LDS 0      /* ablation: extra LDS bytes per workgroup, to lower the occupancy */
 #endif
-    const size_t lds = 16 * sizeof(NsrLevel) + (LAT_LAZY_LEVELS < 16 ? (size_t)a.lat_slots * 4 : 0) + (TS_THREADS / 64) * ts_wave_bytes(a.lat_slots) + NSR_ABL_TS_PAD_LDS;
+    const size_t lds = 16 * sizeof(NsrLevel) + (TS_THREADS / 64) * ts_wave_bytes(a.lat_slots) + NSR_ABL_TS_PAD_LDS;
     static bool attr_set[64] = {};
     int dev = 0;
     (void)hipGetDevice(&dev);
