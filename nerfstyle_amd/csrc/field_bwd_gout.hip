@@ -8,6 +8,7 @@
 //                       the current tile's inputs is waited for at the loop top (else: vmcnt(0) mid-tile)   13.2 -> 11.7 ms
 //   NSR_MM_AHEAD / NSR_BWD_WQ  weight-fragment LDS reads run ahead of the MFMA stream: four in flight inside a layer, the
 //                       next layer's first four requested before the previous layer's packing code          11.7 -> 10.7 ms
+// An 8-deep queue for the two 8-fragment layers: no change (measured).
 // (the tracker unit keeps them off -- its scatter already separates the loads from their use, and the read-ahead costs it
 // registers: 49.4 -> 51.2 ms).
 #define NSR_BWD_TU_GOUT 1
