@@ -465,7 +465,9 @@ k_march_wpr(const float *__restrict__ rays_o, const float *__restrict__ rays_d, 
 // compositing (training)
 // ---------------------------------------------------------------------------------------------
 #define RM_MAXC 16
+#ifndef RM_CU
 #define RM_CU 8u      // composite steps whose loads are issued together
+#endif
 
 // Training composite, coalesced form.  The reference runs one thread per ray over [M, C] arrays
 // (raymarching.cu:806-879, 904-986): every load of a wave touches 64 different lines (measured
