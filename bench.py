@@ -24,6 +24,7 @@ Prints ONE JSON line on rank 0 (contract in the task statement) including `roofl
 The GPU leg is printed to stderr as soon as it is done; the CPU leg runs after it, inside a hard time budget.
 """
 import argparse
+import gc
 import json
 import os
 import statistics
@@ -298,6 +299,10 @@ def run_recon(args, dev, rank, world):
     graph_ev = None
     if args.graph:
         graph_ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+    # the cyclic collector stays out of the timed region (a generation-2 pass over torch's module graph is a 30-60 ms host
+    # pause; the step itself creates no reference cycles): collect now, switch it back on afterwards
+    gc.collect()
+    gc.disable()
     P.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -321,6 +326,7 @@ def run_recon(args, dev, rank, world):
     P.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     profiling.enabled = False
     elapsed = P.max_over_ranks(elapsed, dev)
     prof = profiling.summary()
@@ -472,6 +478,8 @@ def run_style(args, dev, rank, world):
         step(it)
     profiling.reset()
     profiling.enabled = True
+    gc.collect()
+    gc.disable()                            # as in run_recon: no generation-2 collection pause inside the timed region
     P.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -481,6 +489,7 @@ def run_style(args, dev, rank, world):
     P.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     profiling.enabled = False
     elapsed = P.max_over_ranks(elapsed, dev)
     prof = profiling.summary()
