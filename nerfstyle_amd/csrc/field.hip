@@ -12,7 +12,13 @@
 #include "field_common.h"
 
 template <typename TT, int CD, bool SIGMA_ONLY>
+#ifndef NSR_FWD_WAVES_PER_EU
+#define NSR_FWD_WAVES_PER_EU 0
+#endif
 __global__ void __launch_bounds__(256)
+#if NSR_FWD_WAVES_PER_EU
+__attribute__((amdgpu_waves_per_eu(NSR_FWD_WAVES_PER_EU, NSR_FWD_WAVES_PER_EU)))
+#endif
 k_field_fwd(FieldArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     short *wl = reinterpret_cast<short *>(smem);
