@@ -188,6 +188,22 @@ def profile_traffic(args):
     return pm
 
 
+def profile_kernel_share(name, group):
+    """TotalDurationNs of kernel `name` over that of the kernels in `group`, from the committed rocprofv3 summary (None if absent)."""
+    import csv
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r02_bench_kernel_stats.csv')
+    try:
+        tot = {}
+        with open(path) as f:
+            for r in csv.DictReader(f):
+                for g in group:
+                    if g in r['Name']:
+                        tot[g] = tot.get(g, 0.0) + float(r['TotalDurationNs'])
+        return tot[name] / sum(tot.values()) if name in tot and sum(tot.values()) > 0 else None
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def main():
     args = parse()
     from nerfstyle_amd import parallel as P
@@ -380,11 +396,20 @@ def run_recon(args, dev, rank, world):
             # what k_field_bwd actually queues on: memory-side float-atomic requests (TCC_EA0_ATOMIC per sample from the PMC
             # pass in profiles/) against the chip-wide rate tools/atomic_footprint_bench.hip measures
             launches, tot_ms, avg_ms = prof['field_bwd']
-            rate = k['atomic_requests_per_sample'] * samples / max(launches, 1) / (avg_ms * 1e-3) / 1e9
+            share, share_src = 1.0, None
+            if sorted_bwd:
+                # the HIP events bracket the PAIR (one C call launches both kernels): the scatter kernel's share of it comes
+                # from the committed rocprofv3 kernel summary of this command
+                share = profile_kernel_share('k_table_scatter', ('k_table_scatter', 'k_field_bwd'))
+                share_src = 'profiles/r02_bench_kernel_stats.csv' if share else None
+                share = share or 1.0
+            rate = k['atomic_requests_per_sample'] * samples / max(launches, 1) / (avg_ms * share * 1e-3) / 1e9
             extra['atomic_requests_bwd'] = {'bound': 'memory-side atomic unit', 'kernel': 'k_table_scatter' if sorted_bwd else 'k_field_bwd',
                                             'achieved': round(rate, 2),
                                             'peak': 21.06, 'unit': 'G requests/s', 'frac': round(rate / 21.06, 4),
                                             'requests_per_sample': k['atomic_requests_per_sample'],
+                                            'kernel_ms': round(avg_ms * share, 3), 'kernel_share_of_pair': round(share, 4),
+                                            'kernel_share_source': share_src,
                                             'source': 'requests/sample from profiles/ (not this run); peak = measured microbenchmark'}
     elif graph_ev:
         # whole-replay timing: the kernels cannot be event-timed inside a graph; the per-kernel split of this
