@@ -30,6 +30,9 @@
 #define NSR_BWD_PKMAX false
 #endif
 #endif
+#ifndef NSR_BWD_PKMASK
+#define NSR_BWD_PKMASK 0           /* ReLU masks of the backward applied to packed 16-bit pairs (GOUT unit) */
+#endif
 #ifndef NSR_BWD_WQ
 #define NSR_BWD_WQ 0               /* straight-order MLP section with queued weight fragments (GOUT unit) */
 #endif
@@ -154,6 +157,40 @@ __device__ __forceinline__ void field_tr4(const s8v (&x)[2], s4v ident, s4v (&ou
 // 4 gradient tiles -> masked by the forward activation -> two K=32 B fragments
 template <int CD>
 __device__ __forceinline__ void field_mask_pack(const f4v (&gacc)[4], const s8v (&act)[2], s8v (&out)[2]) {
+#if NSR_BWD_PKMASK
+    // Round first, mask afterwards on the packed 16-bit pairs: (act > 0 as a signed 16-bit pattern) -> all-ones / zero by
+    // max(act, 0), negate, arithmetic shift -- three packed instructions per PAIR instead of a compare and a select per
+    // element, and one packed conversion per pair.  Same bits: a masked element is +0 either way, the others are rounded
+    // alike (round to nearest even).  The mask is inline asm: the compiler turns the same arithmetic back into compares and
+    // selects.
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+        const uint4 a4 = __builtin_bit_cast(uint4, act[t]);
+        const uint32_t ap[4] = {a4.x, a4.y, a4.z, a4.w};
+        uint32_t o[4];
+#pragma unroll
+        for (int p = 0; p < 4; p++) {                       // pair p of this fragment: elements 2p, 2p + 1
+            const f4v &g = gacc[2 * t + (p >> 1)];
+            const int e = 2 * (p & 1);
+            // (the conversion is left to the compiler: it reads MFMA results, and only the compiler knows how many wait
+            // states that read needs -- an inline-asm conversion here returned stale accumulators in one instantiation)
+            uint32_t gp, m;
+            if (CD == NSR_F16) {
+                typedef _Float16 hh2 __attribute__((ext_vector_type(2)));
+                const hh2 hp = {(_Float16)g[e], (_Float16)g[e + 1]};
+                gp = __builtin_bit_cast(uint32_t, hp);
+            } else {
+                typedef __bf16 bb2 __attribute__((ext_vector_type(2)));
+                const bb2 bp = {(__bf16)g[e], (__bf16)g[e + 1]};
+                gp = __builtin_bit_cast(uint32_t, bp);
+            }
+            asm("v_pk_max_i16 %0, %1, 0\n\tv_pk_sub_i16 %0, 0, %0\n\tv_pk_ashrrev_i16 %0, 15, %0 op_sel_hi:[0,1]" : "=&v"(m) : "v"(ap[p]));
+            o[p] = gp & m;
+        }
+        out[t] = __builtin_bit_cast(s8v, make_uint4(o[0], o[1], o[2], o[3]));
+    }
+    return;
+#endif
     out[0] = mm_cat(mm_round4<CD, false>(mm_relu_mask(gacc[0], mm_lo(act[0]))),
                     mm_round4<CD, false>(mm_relu_mask(gacc[1], mm_hi(act[0]))));
     out[1] = mm_cat(mm_round4<CD, false>(mm_relu_mask(gacc[2], mm_lo(act[1]))),
@@ -547,7 +584,9 @@ k_field_bwd(FieldBwdArgs b) {
         __builtin_amdgcn_s_waitcnt(0);
 #endif
         NSR_TICK(tk1);
+#if !(defined(NSR_ABL_SECT) && NSR_BWD_WQ)
         NSR_TACC(0, tk0, tk1);
+#endif
         const uint32_t m = tile * 16 + s;
         const bool valid = m < Mc;
         // GOUT writes no LDS inside this loop, so the compiler would hoist the (loop-invariant) weight-fragment LDS reads
@@ -755,6 +794,9 @@ k_field_bwd(FieldBwdArgs b) {
         SCQ_PACE(4);
         mm_layer32_q<CD, 1, 2>(wq, wl + FW_R3, lane, hr2, rgb);
         mm_queue16<4>(wq16, wt + BW_R3T, lane);
+#ifdef NSR_ABL_SECT
+        NSR_TICK(ts1);
+#endif
 
         // ================= upstream gradients in B-fragment form (row = 4g + e) ===============
         s4v dyd, dyr, dyk;
@@ -813,6 +855,9 @@ k_field_bwd(FieldBwdArgs b) {
             field_wgrad<CD, 4, 1>(w_r1, g1t, c1t);
             SCQ_PACE(4);
         }
+#ifdef NSR_ABL_SECT
+        NSR_TICK(ts2);
+#endif
         // transposed encoder features (shared by the color1 / class / density wgrads)
         s4v xct[2], xdt[2];
         field_tr2<CD>(xc, ident, xct);
@@ -852,6 +897,9 @@ k_field_bwd(FieldBwdArgs b) {
             field_wgrad<CD, 4, 2>(w_k1, ght, xct);
             SCQ_PACE(4);
         }
+#ifdef NSR_ABL_SECT
+        NSR_TICK(ts3);
+#endif
         // ================= density: 32 -> 64 -> 1 =============================================
         f4v gxd[2];
         {
@@ -1019,7 +1067,11 @@ k_field_bwd(FieldBwdArgs b) {
         // as the forward encode.  The scatter is VALU + LDS only: its records go to the ring and leave as
         // atomics at the pace points of the NEXT tile's dgrad / wgrad section.
         NSR_TICK(tk2);
+#if defined(NSR_ABL_SECT) && NSR_BWD_WQ
+        NSR_TACC(0, tk1, ts1); NSR_TACC(1, ts1, ts2); NSR_TACC(2, ts2, ts3); NSR_TACC(3, ts3, tk2);
+#else
         NSR_TACC(1, tk1, tk2);
+#endif
         // Next tile's loads go out BEFORE this tile's scatter: the scatter touches LDS only (its records are
         // turned into atomics by the pace points of the next tile), so by the next loop top both these loads
         // and the atomics issued ahead of them (vmcnt retires in order) have had the whole scatter to land.
@@ -1031,7 +1083,9 @@ k_field_bwd(FieldBwdArgs b) {
         if (tile + 1 < w_end) nxt = load_tile(tile + 1, fetch_idx(tile + 1));
 #endif
         NSR_TICK(tk3);
+#if !(defined(NSR_ABL_SECT) && NSR_BWD_WQ)
         NSR_TACC(3, tk2, tk3);
+#endif
         if (td || tc) {
             float4 sg[4];
 #pragma unroll
@@ -1050,7 +1104,9 @@ k_field_bwd(FieldBwdArgs b) {
             else field_scatter_seq(seq, lds_lv, seqG, q, gt1, live ? u0 : 0.f, live ? u1 : 0.f, live ? u2 : 0.f, sg, lane, td, tc);
         }
         NSR_TICK(tk4);
+#if !(defined(NSR_ABL_SECT) && NSR_BWD_WQ)
         NSR_TACC(2, tk3, tk4);
+#endif
         cur = nxt;
 #if NSR_BWD_EARLY_NEXT
         if (GOUT) { idx_cur = idx_next; idx_next = idx_nn; }

@@ -8,6 +8,8 @@
 //                       the current tile's inputs is waited for at the loop top (else: vmcnt(0) mid-tile)   13.2 -> 11.7 ms
 //   NSR_MM_AHEAD / NSR_BWD_WQ  weight-fragment LDS reads run ahead of the MFMA stream: four in flight inside a layer, the
 //                       next layer's first four requested before the previous layer's packing code          11.7 -> 10.7 ms
+//   NSR_BWD_PKMASK      the backward's ReLU masks on packed 16-bit pairs (3 packed instructions per pair instead of a
+//                       compare + select per element; 1412 -> 1304 instructions per tile)                  10.6 -> 10.0 ms
 // An 8-deep queue for the two 8-fragment layers: no change (measured).
 // (the tracker unit keeps them off -- its scatter already separates the loads from their use, and the read-ahead costs it
 // registers: 49.4 -> 51.2 ms).
@@ -20,5 +22,8 @@
 #endif
 #ifndef NSR_BWD_WQ
 #define NSR_BWD_WQ 1
+#endif
+#ifndef NSR_BWD_PKMASK
+#define NSR_BWD_PKMASK 1
 #endif
 #include "field_bwd.hip"
