@@ -10,7 +10,9 @@
 //                       next layer's first four requested before the previous layer's packing code          11.7 -> 10.7 ms
 //   NSR_BWD_PKMASK      the backward's ReLU masks on packed 16-bit pairs (3 packed instructions per pair instead of a
 //                       compare + select per element; 1412 -> 1304 instructions per tile)                  10.6 -> 10.0 ms
-// An 8-deep queue for the two 8-fragment layers: no change (measured).
+// An 8-deep queue for the two 8-fragment layers: no change (measured).  The wgrad operand transposes through LDS
+// (ds_write_b64 + ds_read_b64_tr_b16, 49 per tile) instead of an MFMA with the identity + re-rounding: 1304 -> 1240
+// instructions per tile and the same time (21.4 vs 21.5 ms for the pair) -- the LDS round trips cost what the MFMAs did.
 // (the tracker unit keeps them off -- its scatter already separates the loads from their use, and the read-ahead costs it
 // registers: 49.4 -> 51.2 ms).
 #define NSR_BWD_TU_GOUT 1
