@@ -8,7 +8,8 @@
 // order inside a block -- that the fused field kernels walk instead (`perm` argument): consecutive 16-sample tiles
 // then touch the same few cells on every level, the forward's gathers hit in L2 and the backward accumulates whole
 // lattice tiles in LDS before one merged atomic per corner leaves (field_bwd.hip).  The sample buffers themselves
-// stay in ray order (the composite kernels walk them per ray); only the field kernels go through the permutation.
+// stay in ray order (the composite kernels walk them per ray); only the field kernels go through the permutation
+// (forward, MLP backward and table scatter all walk it: the forward's HBM traffic falls from 1230 to 538 B per sample).
 //
 // The sort is rocPRIM's radix_sort_pairs (a plain library sort of 30-bit keys: 1.9 ms for 47 M pairs on MI355X);
 // the keys are made here.  The number of valid samples lives on the device: `sort_prefix` (host value, <= M) says

@@ -340,8 +340,9 @@ class StyleTCNerf(nn.Module):
     # ---- forward -------------------------------------------------------------------------------
     def field(self, pts, sigma_only=False, m_dev=None, density_scale=1.0, perm=None):
         """Fast path: flat sigmas [M] (and rgbs [M,3+nc]); m_dev = device int32 sample count; perm = spatial order from
-        `sample_order` (int32 [M] device tensor): the backward then accumulates the table gradient in that order with the
-        stand-alone lattice scatter kernel (same result up to fp32 summation order; pays on dense full-frame batches)."""
+        `sample_order` (int32 [M] device tensor): a training forward then walks the samples in that order (its saved features
+        are tile-major in it) and the backward follows -- MLP chain first, then the table gradient with the stand-alone
+        lattice scatter kernel (same result per sample, table gradient up to fp32 summation order; pays on dense batches)."""
         want_feats = bool(self.save_features and torch.is_grad_enabled() and self.arena.requires_grad and not sigma_only)
         return _field.apply(pts, self.arena, self, sigma_only, m_dev, density_scale, want_feats, perm)
 
