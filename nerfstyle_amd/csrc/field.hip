@@ -9,6 +9,12 @@
 // the 8 elements the K=32 MFMA B fragment wants from that lane (features 4g..4g+3 of k-block 0
 // and of k-block 1) -- so encode output feeds the matrix cores with no data movement, and in the
 // backward the MFMA-produced input gradient lands on the lane that owns those levels' scatter.
+// The forward kernel keeps all 32 table gathers of a lane's four levels in flight before it consumes the first (125
+// instead of 74 VGPRs, still 4 waves per SIMD): 8.2 -> 8.0 ms on the bench frame.  Forward only -- the backward's re-gather
+// path shares field_encode and has no registers to spare.
+#ifndef NSR_FWD_BATCH_GATHER
+#define NSR_FWD_BATCH_GATHER 1
+#endif
 #include "field_common.h"
 
 template <typename TT, int CD, bool SIGMA_ONLY>

@@ -167,6 +167,39 @@ __device__ __forceinline__ float4 field_encode_level(const NsrLevel &lv, const T
     return acc;
 }
 
+#ifndef NSR_FWD_BATCH_GATHER
+#define NSR_FWD_BATCH_GATHER 0     /* all 32 gathers of a lane's four levels in flight before the first is used (set by field.hip) */
+#endif
+#if NSR_FWD_BATCH_GATHER
+// rows and weights of one level (the first half of field_encode_level)
+template <bool FAST>
+__device__ __forceinline__ void field_level_rows(const NsrLevel &lv, float u0, float u1, float u2, uint32_t (&rows)[8], float (&w)[8]) {
+    float f[3];
+    uint32_t c[3];
+    nsr_grid_locate(u0, lv.resolution, 1, f[0], c[0]);
+    nsr_grid_locate(u1, lv.resolution, 1, f[1], c[1]);
+    nsr_grid_locate(u2, lv.resolution, 1, f[2], c[2]);
+    const float wxy[4] = {(1 - f[0]) * (1 - f[1]), f[0] * (1 - f[1]), (1 - f[0]) * f[1], f[0] * f[1]};
+    const float wz[2] = {1 - f[2], f[2]};
+    const bool hashed = FAST || lv.use_hash != 0;
+    const uint32_t mulY = hashed ? 2654435761u : lv.mul[1], mulZ = hashed ? 805459861u : lv.mul[2];
+    const uint32_t ty[2] = {c[1] * mulY, (c[1] + 1u) * mulY}, tz[2] = {c[2] * mulZ, (c[2] + 1u) * mulZ};
+#pragma unroll
+    for (uint32_t idx = 0; idx < 8; idx++) {
+        w[idx] = wxy[idx & 3] * wz[idx >> 2];
+        const uint32_t x = c[0] + (idx & 1u), a = ty[(idx >> 1) & 1], b = tz[idx >> 2];
+        if (FAST) {
+            rows[idx] = lv.offset + ((x ^ a ^ b) & (lv.size - 1u));
+        } else {
+            const uint32_t index = hashed ? (x ^ a ^ b) : (x * lv.mul[0] + a + b);
+            const uint32_t t = __umulhi(lv.magic, index);
+            const uint32_t q = (t + ((index - t) >> lv.sh1)) >> lv.sh2;
+            rows[idx] = lv.offset + (index - q * lv.size);
+        }
+    }
+}
+#endif
+
 // Encodes this lane's four levels; returns the two K=32 B fragments (density, colour).
 template <typename TT, int CD, bool SIGMA_ONLY>
 __device__ __forceinline__ void field_encode(const NsrLevel *lds_lv, const TT *__restrict__ tables, float u0, float u1, float u2,
@@ -174,6 +207,41 @@ __device__ __forceinline__ void field_encode(const NsrLevel *lds_lv, const TT *_
     const int lvl[4] = {2 * g, 2 * g + 1, 8 + 2 * g, 9 + 2 * g};
     // levels per call (one per lane group): {0,2,4,6} {1,3,5,7} {8,10,12,14} {9,11,13,15}
     const uint32_t call_levels[4] = {0x0055u, 0x00AAu, 0x5500u, 0xAA00u};
+#if NSR_FWD_BATCH_GATHER
+    if (!SIGMA_ONLY && sizeof(TT) == 2) {
+        uint2 v[4][8];
+        float w[4][8];
+        if (live) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const NsrLevel lv = lds_lv[lvl[i]];
+                uint32_t rows[8];
+                if ((fast_levels & call_levels[i]) == call_levels[i]) field_level_rows<true>(lv, u0, u1, u2, rows, w[i]);
+                else field_level_rows<false>(lv, u0, u1, u2, rows, w[i]);
+#pragma unroll
+                for (int idx = 0; idx < 8; idx++) v[i][idx] = reinterpret_cast<const uint2 *>(tables)[rows[idx]];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (live) {
+#pragma unroll
+                for (int idx = 0; idx < 8; idx++) {
+                    asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,0]" : "+v"(a.x) : "v"(w[i][idx]), "v"(v[i][idx].x));
+                    asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[0,1,0]" : "+v"(a.y) : "v"(w[i][idx]), "v"(v[i][idx].x));
+                    asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,0]" : "+v"(a.z) : "v"(w[i][idx]), "v"(v[i][idx].y));
+                    asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[0,1,0]" : "+v"(a.w) : "v"(w[i][idx]), "v"(v[i][idx].y));
+                }
+            }
+            xd[2 * i + 0] = MM<CD>::cvt(a.x);
+            xd[2 * i + 1] = MM<CD>::cvt(a.y);
+            xc[2 * i + 0] = MM<CD>::cvt(a.z);
+            xc[2 * i + 1] = MM<CD>::cvt(a.w);
+        }
+        return;
+    }
+#endif
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         const NsrLevel lv = lds_lv[lvl[i]];
