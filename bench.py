@@ -58,6 +58,7 @@ def parse():
     ap.add_argument('--compute-dtype', choices=['f16', 'bf16'], default='f16')
     ap.add_argument('--samples-cap', type=int, default=160, help='sample-buffer capacity in samples per ray')
     ap.add_argument('--sparsity-lambda', type=float, default=0.0, help='cfgs: --sparsity_lambda (0.01 in BASELINE configs[3])')
+    ap.add_argument('--no-patch-graphs', action='store_true', help='style stage: launch the patch kernels eagerly (host-bound) instead of replaying graphs')
     ap.add_argument('--fp32-loss', action='store_true', help='style stage: VGG + style loss in fp32 instead of autocast')
     ap.add_argument('--no-occ-update', action='store_true', help='leave the periodic occupancy update out of the step')
     ap.add_argument('--sort-samples', choices=['auto', 'on', 'off'], default='auto',
@@ -482,7 +483,7 @@ def run_style(args, dev, rank, world):
     opt = FusedAdam(model, lr=0.1, keywords=['x_color_embedder'])
     loss_scale = 65536.0 if args.compute_dtype == 'f16' else 1.0
     n_patches = len(patch_list(W, H, 200))
-    patch_graphs = {} if args.graph else None                                  # --graph: one hipGraph per patch shape in pass 2
+    patch_graphs = None if args.no_patch_graphs else {}                        # pass 2: two hipGraphs per patch shape (graph.GraphedPatchBackward)
     total_samples = torch.zeros(1, dtype=torch.int64, device=dev)
 
     def step(it):
@@ -536,9 +537,11 @@ def run_style(args, dev, rank, world):
         'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True,
         'scaling': 'strong', 'vs_baseline': None, 'dtype': args.compute_dtype, 'data': 'synthetic',
         'config': {
-            'workload': "LLFF '{}' stylisation stage, {}x{} frame per iteration: 1 full-frame no-grad pass + VGG16-relu3 content / "
-                        "semantic-NNFM loss (PyTorch, " + ('fp32' if args.fp32_loss else 'autocast ' + args.compute_dtype) + ") + {} deferred-backprop patches of 200x200, colour table only, max_steps {}; random "
-                        "seeded VGG weights, style image and segment maps (none exist offline)".format(args.scene, W, H, n_patches, rcfg.max_steps),
+            'workload': ("LLFF '{}' stylisation stage, {}x{} frame per iteration: 1 full-frame no-grad pass + VGG16-relu3 content / "
+                         "semantic-NNFM loss (PyTorch, {}) + {} {} deferred-backprop patches of 200x200, colour table only, max_steps {}; "
+                         "random seeded VGG weights, style image and segment maps (none exist offline)").format(
+                             args.scene, W, H, 'fp32' if args.fp32_loss else 'autocast ' + args.compute_dtype, n_patches,
+                             'eager' if args.no_patch_graphs else 'graph-replayed', rcfg.max_steps),
             'rays_per_step': W * H, 'patches': n_patches, 'max_steps': rcfg.max_steps, 'num_classes': nc,
             'table_dtype': args.table_dtype, 'mfma_dtype': args.compute_dtype,
             'parallelism': 'patches + pass-1 pixel rows sharded x{}, packed colour-table gradient all-reduce'.format(world),
