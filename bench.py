@@ -58,6 +58,7 @@ def parse():
     ap.add_argument('--compute-dtype', choices=['f16', 'bf16'], default='f16')
     ap.add_argument('--samples-cap', type=int, default=160, help='sample-buffer capacity in samples per ray')
     ap.add_argument('--sparsity-lambda', type=float, default=0.0, help='cfgs: --sparsity_lambda (0.01 in BASELINE configs[3])')
+    ap.add_argument('--no-prefetch', action='store_true', help="recon stage: do not overlap the next step's march + sample sort with the backward")
     ap.add_argument('--no-patch-graphs', action='store_true', help='style stage: launch the patch kernels eagerly (host-bound) instead of replaying graphs')
     ap.add_argument('--fp32-loss', action='store_true', help='style stage: VGG + style loss in fp32 instead of autocast')
     ap.add_argument('--no-occ-update', action='store_true', help='leave the periodic occupancy update out of the step')
@@ -288,20 +289,33 @@ def run_recon(args, dev, rank, world):
         perm_state['pos'] = p0 + n_rays
         return perm_state['perm'][p0:p0 + n_rays]
 
+    # The march + sample sort of step i+1 do not depend on the parameters: Renderer.prefetch_train runs them on a side stream
+    # while the backward of step i is in flight (same kernels, same results; --no-prefetch switches it off).
+    nxt = {}
+
+    def inputs(it):
+        if it not in nxt:
+            nxt.clear()
+            nxt[it] = (poses[(it * 7 + rank) % poses.shape[0]], draw_pixels())
+        return nxt[it]
+
     def step(it):
-        frame = (it * 7 + rank) % poses.shape[0]
-        pix = draw_pixels()
+        pose, pix = inputs(it)
         if graphed is not None:
-            loss = graphed(poses[frame], pix)
+            loss = graphed(pose, pix)
+            cnt = r._last_counter
         else:
-            out = r.render(poses[frame], None, training=True, pix_subset=pix)
+            out = r.render(pose, None, training=True, pix_subset=pix)
+            cnt = r._last_counter           # (this render's device-side sample count: the prefetch below starts the next march)
             loss = loss_fn(out, pix)
+            if not args.no_prefetch:
+                nxt_pose, nxt_pix = inputs(it + 1)
+                r.prefetch_train(nxt_pose, nxt_pix)
             loss.backward()
         if world > 1:
             P.sync_gradients(model)
         opt.param_groups[0]['lr'] = exp_lr(1e-2, it, 30000)
         opt.step(grad_scale=loss_scale)
-        cnt = r._last_counter
         total_samples.add_(cnt[0].to(torch.int64))
         overflow.add_((cnt[0] >= r.sample_capacity(n_rays)).to(torch.int64))
         return loss.detach()           # not the graph: whatever its nodes still hold would stay allocated over the next step
@@ -384,6 +398,10 @@ def run_recon(args, dev, rank, world):
         dom = max(prof.items(), key=lambda kv: kv[1][1])[0]
         if dom in bytes_per_sample:
             roofline = roof(dom, prof[dom][0], prof[dom][2])
+            if dom == 'field_bwd' and graphed is None and not args.no_prefetch:
+                roofline['concurrent_with'] = ("the next step's march + sample sort on a side stream (Renderer.prefetch_train): the span "
+                                               "includes the time this kernel shares the chip with them; with --no-prefetch the pair "
+                                               "runs alone (~1 ms shorter) and the step is ~1 ms longer")
         if 'field_fwd' in prof:
             launches, tot_ms, avg_ms = prof['field_fwd']
             extra['hash_gather_fwd'] = roof('field_fwd', launches, avg_ms)
@@ -441,6 +459,7 @@ def run_recon(args, dev, rank, world):
             'occupancy': ('device-side update every {} steps inside the step (full update: {} sigma queries); the march reads the seeded '
                           'synthetic bitfield (random-init model has no scene)'.format(rcfg.update_iter, r.cascade * rcfg.grid_size ** 3)
                           if not args.no_occ_update else 'fixed synthetic bitfield, no update'),
+            'prefetch': (not args.no_prefetch) and graphed is None,
             'table_scatter': ('spatial order (nsr_sample_order + stand-alone lattice scatter kernel)'
                               if r._use_spatial_order(n_rays, False) else 'ray order (run tracker, fused)'),
             'sample_capacity_overflows': int(overflow.item()), 'final_loss': float(loss.detach()) / loss_scale * world,

@@ -727,3 +727,41 @@ def test_style_criterion_autocast_close_to_fp32(dev):
             if style_lambda == 0.0:
                 cos = float(torch.dot(gv, g32) / (gv.norm() * g32.norm()))
                 assert cos > tol_cos, (amp, cos)
+
+
+def test_prefetched_march_equals_plain_render(O, dev):
+    """Renderer.prefetch_train (march + compaction + sample order of the next render on a side stream) followed by the
+    matching render gives bit-identical outputs and the same gradient as the plain render; a non-matching render discards it;
+    nothing is prefetched in front of an occupancy update."""
+    r, ref, poses, intr, bits = _setup(dev, cap=256)
+    m = r.model
+    r.sort_samples = True
+    g = torch.Generator().manual_seed(9)
+    pix = torch.randperm(intr.w * intr.h, generator=g)[:30000].to(dev)
+    pose = torch.tensor(poses[2], device=dev)
+    tgt = torch.rand(30000, 3, generator=g).to(dev)
+
+    def grads(prefetch):
+        m._ensure_grad()
+        m.arena.grad.zero_()
+        if prefetch:
+            assert r.prefetch_train(pose, pix)
+        out = r.render(pose, None, training=True, pix_subset=pix)
+        assert getattr(r, '_prefetched', None) is None
+        torch.mean((out['rgb_map'] - tgt) ** 2).backward()
+        return out['rgb_map'].detach().clone(), out['classes'].detach().clone(), m.arena.grad.clone()
+
+    rgb0, cls0, g0 = grads(False)
+    rgb1, cls1, g1 = grads(True)
+    assert torch.equal(rgb0, rgb1) and torch.equal(cls0, cls1)
+    assert float(g0.abs().sum()) > 0 and rel_l2(g1.cpu().numpy(), g0.cpu().numpy()) < 1e-5
+    # a render of something else drops the prefetched march
+    assert r.prefetch_train(pose, pix)
+    other = torch.tensor(poses[3], device=dev)
+    out = r.render(other, None, training=True, pix_subset=pix)
+    assert r._prefetched is None and not torch.equal(out['rgb_map'].detach(), rgb0)
+    # in front of an occupancy update nothing is prefetched
+    r.update_occ = True
+    r.local_step = r.cfg.update_iter * 3
+    assert not r.prefetch_train(pose, pix)
+    r.update_occ = False
