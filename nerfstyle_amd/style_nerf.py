@@ -357,10 +357,15 @@ class StyleTCNerf(nn.Module):
             # on the model that a later call with another M replaces
             ws = torch.empty(need, dtype=torch.int32, device=dev)
         else:
-            ws = getattr(self, '_order_ws', None)
+            # one workspace per stream: Renderer.prefetch_train sorts on a side stream, and a sort on the current stream may
+            # run at the same time (two sorts sharing rocPRIM's temporary storage corrupt each other: a memory fault)
+            if not isinstance(getattr(self, '_order_ws', None), dict):
+                self._order_ws = {}
+            key = torch.cuda.current_stream(dev).cuda_stream
+            ws = self._order_ws.get(key)
             if ws is None or ws.device != dev or ws.numel() < need:
-                self._order_ws = None
-                ws = self._order_ws = torch.empty(need, dtype=torch.int32, device=dev)
+                self._order_ws.pop(key, None)
+                ws = self._order_ws[key] = torch.empty(need, dtype=torch.int32, device=dev)
         ws_ptr = (ws.data_ptr() + 255) & ~255
         perm = torch.empty(M, dtype=torch.int32, device=dev) if out is None else out
         assert perm.dtype == torch.int32 and perm.numel() == M and perm.is_contiguous() and perm.device == dev
