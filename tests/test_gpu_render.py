@@ -755,11 +755,23 @@ def test_prefetched_march_equals_plain_render(O, dev):
     rgb1, cls1, g1 = grads(True)
     assert torch.equal(rgb0, rgb1) and torch.equal(cls0, cls1)
     assert float(g0.abs().sum()) > 0 and rel_l2(g1.cpu().numpy(), g0.cpu().numpy()) < 1e-5
-    # a render of something else drops the prefetched march
-    assert r.prefetch_train(pose, pix)
+    # a render of something else drops the prefetched march -- and its own march + sort, which may run at the same time as
+    # the prefetched ones on the side stream (one rocPRIM workspace per stream), are not disturbed by them
     other = torch.tensor(poses[3], device=dev)
+    ref_other = r.render(other, None, training=True, pix_subset=pix)['rgb_map'].detach().clone()
+    torch.cuda.synchronize()
+    assert r.prefetch_train(pose, pix)
     out = r.render(other, None, training=True, pix_subset=pix)
     assert r._prefetched is None and not torch.equal(out['rgb_map'].detach(), rgb0)
+    assert torch.equal(out['rgb_map'].detach(), ref_other)
+    m.arena.grad.zero_()
+    torch.mean((out['rgb_map'] - tgt) ** 2).backward()
+    g_conc = m.arena.grad.clone()
+    m.arena.grad.zero_()
+    torch.cuda.synchronize()
+    o2 = r.render(other, None, training=True, pix_subset=pix)
+    torch.mean((o2['rgb_map'] - tgt) ** 2).backward()
+    assert rel_l2(g_conc.cpu().numpy(), m.arena.grad.cpu().numpy()) < 1e-5
     # in front of an occupancy update nothing is prefetched
     r.update_occ = True
     r.local_step = r.cfg.update_iter * 3
