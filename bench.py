@@ -58,13 +58,14 @@ def parse():
     ap.add_argument('--compute-dtype', choices=['f16', 'bf16'], default='f16')
     ap.add_argument('--samples-cap', type=int, default=160, help='sample-buffer capacity in samples per ray')
     ap.add_argument('--sparsity-lambda', type=float, default=0.0, help='cfgs: --sparsity_lambda (0.01 in BASELINE configs[3])')
-    ap.add_argument('--no-prefetch', action='store_true', help="recon stage: do not overlap the next step's march + sample sort with the backward")
     ap.add_argument('--no-patch-graphs', action='store_true', help='style stage: launch the patch kernels eagerly (host-bound) instead of replaying graphs')
     ap.add_argument('--fp32-loss', action='store_true', help='style stage: VGG + style loss in fp32 instead of autocast')
     ap.add_argument('--no-occ-update', action='store_true', help='leave the periodic occupancy update out of the step')
     ap.add_argument('--sort-samples', choices=['auto', 'on', 'off'], default='auto',
                     help="spatially ordered table scatter in the backward (nsr_sample_order): 'auto' = batches of >= 140 000 rays, dense pixel sets from 16 384")
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--psnr-rays', type=int, default=4096, help='rays of the PSNR-vs-oracle check after the timed region (0: skip)')
+    ap.add_argument('--no-loss-scaler', action='store_true', help='constant loss scale, no inf/nan check (round 2 behaviour)')
     ap.add_argument('--graph', action='store_true',
                     help='replay the render+loss+backward part of the step as one captured hipGraph (small-batch series)')
     ap.add_argument('--cpu-budget-s', type=float, default=12.0)
@@ -206,8 +207,61 @@ def profile_kernel_share(name, group):
         return None
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` without torchrun: start N fresh rank processes (decided from the environment BEFORE anything
+    touches the GPU; this parent never does), one per GPU, rendezvous on 127.0.0.1; rank 0 prints the JSON line to the inherited
+    stdout.  Exit code = the worst child's."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for rank in range(args.gpus):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(args.gpus), MASTER_ADDR='127.0.0.1',
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    return rc
+
+
+def psnr_vs_oracle(r, poses_np, intr, nc, n_rays):
+    """BASELINE.json's second metric: PSNR of the build's render against the reference render on the identical checkpoint and
+    pose.  The reference cannot run here, so the checker is the fp32 CPU oracle pipeline (oracle/: march -> hash encode ->
+    MLPs -> composite -> epilogue) on the model's CURRENT parameters, `n_rays` fixed pixels of frame 0, outside the timed
+    region.  The product side is Renderer.render(training=False) -- the path that produces test renders."""
+    from oracle import oracle as O
+    m = r.model
+    rng = np.random.default_rng(12345)
+    pix = np.sort(rng.choice(intr.w * intr.h, n_rays, replace=False))
+    dev = r.device
+    with torch.no_grad():
+        out = r.render(torch.tensor(poses_np[0], device=dev), None, training=False, pix_subset=torch.tensor(pix, device=dev))
+    rgb = out['rgb_map'].float().cpu().numpy()
+    sd = {k: v.detach().float().cpu().numpy() for k, v in m.state_dict().items()}
+    ro, rd = O.generate_rays(poses_np[0], intr.w, intr.h, intr.fx, intr.fy, intr.cx, intr.cy, 3, pix_indices=pix)
+    near, far = O.near_far_from_aabb(ro, rd, np.array([-2, -2, -2, 2, 2, 2], np.float32), r.cfg.min_near)
+    xyzs, _, deltas, rays, cnt = O.march_rays_train(ro, rd, 2.0, r.march_bitfield.cpu().numpy(), r.cascade, r.cfg.grid_size, near, far,
+                                                    r.cfg.max_steps, align=128)
+    fp = O.FieldParams(sd['x_density_embedder.embeddings'], sd['x_color_embedder.embeddings'], sd['density_net.params'],
+                       sd['color1_net.params'], sd['color2_net.params'], sd['class_net.params'],
+                       m._offsets_np, m.per_level_scale, num_classes=nc)
+    o, sig, _ = O.field_forward(fp, xyzs)
+    ws, depth, image = O.composite_rays_train_forward(sig * np.float32(r.cfg.density_scale), o, deltas, rays, r.cfg.t_thresh)
+    rgb_o, _, _ = O.render_epilogue(ws, depth, image, near, far)
+    mse = float(np.mean((rgb - rgb_o) ** 2))
+    return {'psnr_vs_oracle_db': round(float(O.compute_psnr(max(mse, 1e-14))), 2), 'psnr_rays': int(n_rays),
+            'psnr_samples': int(cnt[0]), 'psnr_mean_opacity': round(float(ws.mean()), 4),
+            'psnr_note': 'inference render of the final parameters (f16/bf16 MFMA, table dtype as benchmarked) vs the fp32 CPU '
+                         'oracle pipeline on the same parameters, pose 0, fixed pixels; computed after the timed region'}
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and 'RANK' not in os.environ:
+        sys.exit(self_launch(args))
     from nerfstyle_amd import parallel as P
     # rehearsal knobs (NOT used by the driver): run N ranks on ONE GPU over gloo to exercise the N > 1
     # code path on a 1-GPU box -- NSR_BENCH_BACKEND=gloo NSR_BENCH_DEVICE=0
@@ -217,13 +271,17 @@ def main():
     dev_index = int(os.environ.get('NSR_BENCH_DEVICE', local_rank))
     torch.cuda.set_device(dev_index)
     rank, local_rank, world = P.init(backend, seed=args.seed)
-    assert world == args.gpus, 'launch with torchrun --nproc-per-node {} (WORLD_SIZE={})'.format(args.gpus, world)
+    assert world == args.gpus, '--gpus {} but WORLD_SIZE={} (launch plainly, or with torchrun --nproc-per-node {})'.format(
+        args.gpus, world, args.gpus)
     dev = torch.device('cuda', dev_index)
     if args.stage == 'style':
         result = run_style(args, dev, rank, world)
     else:
         result = run_recon(args, dev, rank, world)
     if rank == 0:
+        import torch.distributed as dist
+        result['rccl_ranks'] = dist.get_world_size() if dist.is_initialized() else 1
+        result['dist_backend'] = dist.get_backend() if dist.is_initialized() else 'none (single process)'
         print('[bench] gpu leg done: ' + json.dumps(result), file=sys.stderr, flush=True)
         if world == 1 and not args.no_cpu_baseline:
             result['cpu_baseline'] = cpu_baseline(args.cpu_budget_s, args.num_classes)
@@ -237,11 +295,15 @@ def main():
 def run_recon(args, dev, rank, world):
     from nerfstyle_amd import parallel as P
     from nerfstyle_amd import profiling
-    from nerfstyle_amd.optim import FusedAdam, exp_lr
+    from nerfstyle_amd.optim import FusedAdam, LossScaler, exp_lr
     model, r, rcfg, poses, intr = build(args, dev, rank)
     nc = args.num_classes
-    # loss scaling as the reference's GradScaler (init scale 65536) when the MFMA chain is f16
+    # The reference's GradScaler (trainers/base.py:228,420-425: init scale 65536, inf/nan check + skip + back-off / growth every
+    # step), device-side: optim.LossScaler.  Enabled when the MFMA chain is f16 (bf16 needs no scaling: GradScaler(enabled=False)).
+    # The check (one streaming pass over the gradient arena) and the policy kernel run INSIDE the timed step.
     loss_scale = 65536.0 if args.compute_dtype == 'f16' else 1.0
+    scaler = None if args.no_loss_scaler else LossScaler(init_scale=65536.0, enabled=(args.compute_dtype == 'f16'))
+    scale_t = scaler.scale_tensor(dev) if scaler is not None else None
     opt = FusedAdam(model, lr=1e-2, betas=(0.9, 0.999), eps=1e-15, ema_decay=0.95)
     npix = intr.w * intr.h
     n_rays = min(args.rays_per_gpu, npix)
@@ -268,7 +330,7 @@ def run_recon(args, dev, rank, world):
             pts = torch.rand(sp_n, 3, device=dev, generator=gen) * 4.0 - 2.0
             sig = model(pts)
             total = total + torch.mean(torch.abs(1 - torch.exp(-sp_coeff * sig))) * sp_lambda
-        return total * (loss_scale / world)
+        return total * (scale_t / world) if scale_t is not None else total * (loss_scale / world)
 
     graphed = None
     if args.graph:
@@ -289,15 +351,8 @@ def run_recon(args, dev, rank, world):
         perm_state['pos'] = p0 + n_rays
         return perm_state['perm'][p0:p0 + n_rays]
 
-    # The march + sample sort of step i+1 do not depend on the parameters: Renderer.prefetch_train runs them on a side stream
-    # while the backward of step i is in flight (same kernels, same results; --no-prefetch switches it off).
-    nxt = {}
-
     def inputs(it):
-        if it not in nxt:
-            nxt.clear()
-            nxt[it] = (poses[(it * 7 + rank) % poses.shape[0]], draw_pixels())
-        return nxt[it]
+        return poses[(it * 7 + rank) % poses.shape[0]], draw_pixels()
 
     def step(it):
         pose, pix = inputs(it)
@@ -306,16 +361,16 @@ def run_recon(args, dev, rank, world):
             cnt = r._last_counter
         else:
             out = r.render(pose, None, training=True, pix_subset=pix)
-            cnt = r._last_counter           # (this render's device-side sample count: the prefetch below starts the next march)
+            cnt = r._last_counter           # this render's device-side sample count
             loss = loss_fn(out, pix)
-            if not args.no_prefetch:
-                nxt_pose, nxt_pix = inputs(it + 1)
-                r.prefetch_train(nxt_pose, nxt_pix)
             loss.backward()
         if world > 1:
-            P.sync_gradients(model)
-        opt.param_groups[0]['lr'] = exp_lr(1e-2, it, 30000)
-        opt.step(grad_scale=loss_scale)
+            P.sync_gradients(model, optimizer=opt)
+        if scaler is not None:
+            opt.step(scaler=scaler, lr_decay_steps=30000)      # lr = 1e-2 * 0.1^(steps / 30000), on the device
+        else:
+            opt.param_groups[0]['lr'] = exp_lr(1e-2, it, 30000)
+            opt.step(grad_scale=loss_scale)
         total_samples.add_(cnt[0].to(torch.int64))
         overflow.add_((cnt[0] >= r.sample_capacity(n_rays)).to(torch.int64))
         return loss.detach()           # not the graph: whatever its nodes still hold would stay allocated over the next step
@@ -398,10 +453,6 @@ def run_recon(args, dev, rank, world):
         dom = max(prof.items(), key=lambda kv: kv[1][1])[0]
         if dom in bytes_per_sample:
             roofline = roof(dom, prof[dom][0], prof[dom][2])
-            if dom == 'field_bwd' and graphed is None and not args.no_prefetch:
-                roofline['concurrent_with'] = ("the next step's march + sample sort on a side stream (Renderer.prefetch_train): the span "
-                                               "includes the time this kernel shares the chip with them; with --no-prefetch the pair "
-                                               "runs alone (~1 ms shorter) and the step is ~1 ms longer")
         if 'field_fwd' in prof:
             launches, tot_ms, avg_ms = prof['field_fwd']
             extra['hash_gather_fwd'] = roof('field_fwd', launches, avg_ms)
@@ -441,6 +492,9 @@ def run_recon(args, dev, rank, world):
                     'avg_launch_ms': round(ms, 4), 'algorithmic_bytes_per_sample': bytes_per_sample['field_fwd'] + bytes_per_sample['field_bwd'],
                     'samples_per_launch': int(samples / args.steps),
                     'note': 'small-batch steps are launch/latency-bound, not bandwidth-bound; per-kernel split in profiles/'}
+    psnr = {}
+    if args.psnr_rays > 0 and world == 1:
+        psnr = psnr_vs_oracle(r, poses.cpu().numpy(), intr, nc, args.psnr_rays)
     wl = "LLFF '{}' reconstruction stage, {}x{} frames, {} rays/step/GPU, synthetic occupancy (28 seeded boxes), {:.1f} samples/ray".format(
         args.scene, intr.w, intr.h, n_rays, spr)
     if sp_lambda > 0:
@@ -459,14 +513,17 @@ def run_recon(args, dev, rank, world):
             'occupancy': ('device-side update every {} steps inside the step (full update: {} sigma queries); the march reads the seeded '
                           'synthetic bitfield (random-init model has no scene)'.format(rcfg.update_iter, r.cascade * rcfg.grid_size ** 3)
                           if not args.no_occ_update else 'fixed synthetic bitfield, no update'),
-            'prefetch': (not args.no_prefetch) and graphed is None,
             'table_scatter': ('spatial order (nsr_sample_order + stand-alone lattice scatter kernel)'
                               if r._use_spatial_order(n_rays, False) else 'ray order (run tracker, fused)'),
-            'sample_capacity_overflows': int(overflow.item()), 'final_loss': float(loss.detach()) / loss_scale * world,
+            'sample_capacity_overflows': int(overflow.item()),
+            'final_loss': float(loss.detach()) / (scaler.get_scale() if scaler is not None else loss_scale) * world,
+            'grad_scaler': ({'device_side': True, 'enabled': scaler.enabled, 'scale': scaler.get_scale(), 'steps_skipped': scaler.steps_skipped(),
+                             'steps_taken': opt.steps_taken} if scaler is not None else 'constant scale, no inf/nan check'),
         },
         'kernel_ms_per_step': {k: round(v[1] / args.steps, 4) for k, v in sorted(prof.items())},
         'roofline': roofline,
         'rooflines_other': extra,
+        **psnr,
     }
 
 
@@ -480,7 +537,7 @@ def run_style(args, dev, rank, world):
     from nerfstyle_amd import parallel as P
     from nerfstyle_amd import profiling
     from nerfstyle_amd.losses import SemanticStyleLoss
-    from nerfstyle_amd.optim import FusedAdam
+    from nerfstyle_amd.optim import FusedAdam, LossScaler
     from nerfstyle_amd.stylize import StyleCriterion, deferred_backprop_step, patch_list
     from nerfstyle_amd.vgg import VGG16FeatureExtractor
     if args.max_steps is None:
@@ -500,9 +557,11 @@ def run_style(args, dev, rank, world):
     crit = StyleCriterion(fx, SemanticStyleLoss(['relu3'], clusters=seg), content_lambda=0.001, style_lambda=1.0, amp_dtype=amp)
     crit.init_style(style, num_classes=nc)
     opt = FusedAdam(model, lr=0.1, keywords=['x_color_embedder'])
-    loss_scale = 65536.0 if args.compute_dtype == 'f16' else 1.0
+    # trainers/style.py:200-204: scaler.step / scaler.update every iteration -- device-side here (optim.LossScaler)
+    scaler = LossScaler(init_scale=65536.0, enabled=(args.compute_dtype == 'f16'))
+    loss_scale = scaler.scale_tensor(dev)
     n_patches = len(patch_list(W, H, 200))
-    patch_graphs = None if args.no_patch_graphs else {}                        # pass 2: two hipGraphs per patch shape (graph.GraphedPatchBackward)
+    patch_graphs = None if args.no_patch_graphs else {}                        # pass 2: one hipGraph per patch shape (graph.GraphedPatchBackward)
     total_samples = torch.zeros(1, dtype=torch.int64, device=dev)
 
     def step(it):
@@ -515,8 +574,8 @@ def run_style(args, dev, rank, world):
         def image_loss(rgb, classes):
             return crit(rgb, targets[frame], classes, frame_key=frame, it=it)[0]
         loss, _ = deferred_backprop_step(r, poses[frame], image_loss, patch_size=200, loss_scale=loss_scale, rank=rank, world=world,
-                                         with_classes=True, patch_graphs=patch_graphs)
-        opt.step(grad_scale=loss_scale)
+                                         optimizer=opt, with_classes=True, patch_graphs=patch_graphs)
+        opt.step(scaler=scaler)
         return loss
 
     for it in range(args.warmup):

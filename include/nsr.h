@@ -12,9 +12,11 @@
  * Contract (same as the reference's):
  *   - plain C, raw DEVICE pointers + explicit sizes + a HIP stream; no torch types;
  *   - the caller allocates every output and every workspace; the library never allocates,
- *     frees or retains device memory and keeps no state (re-entrant, thread-safe);
- *   - no host synchronisation, no host reads of device data: every call is legal inside
- *     hipGraph stream capture;
+ *     frees or retains device memory and keeps no state between calls (re-entrant, thread-safe).
+ *     The one exception is a per-device "attribute already set" flag beside the two kernels that ask
+ *     for more than the default LDS (hipFuncSetAttribute is idempotent: a racing second call is harmless);
+ *   - no host synchronisation, no host reads of device data, no library calls (round 3: the sample sort
+ *     is the library's own, rocPRIM is gone): every call is legal inside hipGraph stream capture;
  *   - returns an int status (0 = ok, <0 = error) and never throws; the reference returns void
  *     and raises c10::Error / std::runtime_error (gridencoder.cu:369,387,414,433,440-487) --
  *     the Python wrappers turn a negative status into RuntimeError.
@@ -253,9 +255,11 @@ uint64_t nsr_field_backward_workspace_bytes(uint32_t M, int with_perm);
 
 /* Spatial processing order of marched samples (no reference counterpart; see csrc/sample_order.hip): perm [M] u32 =
  * indices of the first min(m_dev[0], M) samples in Morton order of their encoder input (10 bits per axis, stable: ray
- * order inside a 4^3-finest-cell block), followed by the remaining slots.  sort_prefix <= M: how many leading slots
- * take part in the sort (the emitted count lives on the device; pass an estimate >= it, or M; a smaller value is still
- * correct -- the slots past it keep identity order).  Consumed by nsr_field_backward (table scatter in spatial order).
+ * order inside a 4^3-finest-cell block), followed by the remaining slots in identity order.  sort_prefix <= M caps the
+ * number of leading slots that take part in the sort; the kernels bound themselves by min(m_dev[0], sort_prefix) on the
+ * device, so M is the normal value (a smaller one is still correct: the slots past it keep identity order).  The sort is
+ * the library's own 3 x 10-bit LSD radix sort: stream-ordered, no host call, capture-safe, deterministic.
+ * Consumed by nsr_field_forward / nsr_field_backward (spatial walk, table scatter in spatial order).
  * workspace: nsr_sample_order_workspace_bytes(M) bytes, 256-byte aligned.  bbox_min / bbox_size: HOST float[3]. */
 uint64_t nsr_sample_order_workspace_bytes(uint32_t M);
 int nsr_sample_order(const float *xyzs, uint32_t M, const int32_t *m_dev, uint32_t sort_prefix,
@@ -277,6 +281,33 @@ int nsr_adam_step(float *params, float *grads, float *exp_avg, float *exp_avg_sq
                   void *half_copy, uint64_t n, float lr, float beta1, float beta2, float eps,
                   float grad_scale_inv, float ema_decay, uint32_t step, uint32_t elem_mask4,
                   nsr_stream_t stream);
+
+/* Device-side GradScaler + optimiser bookkeeping (replaces scaler.step(optim) / scaler.update() / scheduler.step(),
+ * trainers/base.py:228,420-425 and trainers/style.py:200-204, which read the inf flag back to the host every step).
+ * scaler_state: device buffer of 16 32-bit words, kept by the caller across steps:
+ *   [0] f32 loss scale (initialise to 65536, GradScaler's default)   [1] i32 growth tracker   [2] u32 found_inf
+ *   [3] u32 optimiser steps taken   [4] u32 steps skipped   [8..12] this step's values for nsr_adam_step_scaled
+ *   (skip flag, lr / (1 - beta1^t), 1 / sqrt(1 - beta2^t), 1 / scale, lr); other words reserved, initialise to 0.
+ * One optimiser step =
+ *   nsr_grad_check        per trained region: sets found_inf if any element selected by elem_mask4 is inf / nan
+ *                         (GradScaler.unscale_'s check; untrained regions are not looked at, so data-parallel ranks
+ *                         that all-reduce only the trained regions take the same decision);
+ *   nsr_scaler_update     one thread: skip decision, scale *= backoff and tracker = 0 on inf, else step count += 1,
+ *                         tracker += 1, scale *= growth every growth_interval clean steps; lr = lr_base *
+ *                         0.1^((t-1) / lr_decay_steps) (LambdaLR advanced only on steps that were not skipped;
+ *                         lr_decay_steps <= 0: constant) and Adam's bias corrections for step t, in double precision;
+ *                         enabled == 0: never skips, scale stays 1 (GradScaler(enabled=False)); clears found_inf;
+ *   nsr_adam_step_scaled  per trained region: nsr_adam_step with those device-side scalars; on a skipped step the
+ *                         parameters and moments stay, the gradient is still zeroed and the EMA still moves
+ *                         (ema.update() is unconditional, base.py:426).  half_copy covers the first half_n elements.
+ * Nothing is read on the host: legal under stream capture. */
+int nsr_grad_check(const float *grads, uint64_t n, uint32_t elem_mask4, void *scaler_state, nsr_stream_t stream);
+int nsr_scaler_update(void *scaler_state, float lr_base, float lr_decay_steps, float beta1, float beta2,
+                      float growth_factor, float backoff_factor, uint32_t growth_interval, int enabled,
+                      nsr_stream_t stream);
+int nsr_adam_step_scaled(float *params, float *grads, float *exp_avg, float *exp_avg_sq, float *ema,
+                         void *half_copy, uint64_t n, uint64_t half_n, float beta1, float beta2, float eps,
+                         float ema_decay, uint32_t elem_mask4, const void *scaler_state, nsr_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Occupancy-grid update on the device: replaces Renderer.update_state / _compute_occ_sigmas

@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get('NSR_LIB_PATH') or os.path.join(_HERE, 'libnsr_hip.so'
 
 NSR_F32, NSR_F16, NSR_BF16 = 0, 1, 2
 NSR_ACT_NONE, NSR_ACT_SIGMOID = 0, 1
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _DT = {torch.float32: NSR_F32, torch.float16: NSR_F16, torch.bfloat16: NSR_BF16}
 
@@ -70,6 +70,9 @@ SIGNATURES = {
     'nsr_sample_order': (i32, [vp, u32, vp, u32, ctypes.POINTER(f32), ctypes.POINTER(f32), vp, vp, vp]),
     'nsr_cast_f32_to_f16': (i32, [vp, vp, u64, vp]),
     'nsr_adam_step': (i32, [vp, vp, vp, vp, vp, vp, u64, f32, f32, f32, f32, f32, f32, u32, u32, vp]),
+    'nsr_grad_check': (i32, [vp, u64, u32, vp, vp]),
+    'nsr_scaler_update': (i32, [vp, f32, f32, f32, f32, f32, f32, u32, i32, vp]),
+    'nsr_adam_step_scaled': (i32, [vp, vp, vp, vp, vp, vp, u64, u64, f32, f32, f32, f32, u32, vp, vp]),
     'nsr_occ_workspace_bytes': (u64, [u32, u32]),
     'nsr_occ_num_points': (u32, [u32, u32, i32]),
     'nsr_occ_sample_points': (i32, [vp, u32, u32, f32, i32, u64, u32, vp, vp, vp, vp, vp, vp]),

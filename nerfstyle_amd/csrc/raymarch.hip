@@ -849,7 +849,7 @@ const char *nsr_status_string(int status) {
         default: return "unknown status";
     }
 }
-int nsr_abi_version(void) { return 2; }
+int nsr_abi_version(void) { return 3; }
 const char *nsr_target_arch(void) { return "gfx950"; }
 
 int nsr_near_far_from_aabb(const float *rays_o, const float *rays_d, const float *aabb, uint32_t N, float min_near,

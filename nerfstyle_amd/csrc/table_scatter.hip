@@ -23,11 +23,6 @@
 #include "field_common.h"
 #include "table_scatter.h"
 
-#ifdef NSR_ABL_STATS
-#define NSR_STAT(i, n) do { } while (0)
-#else
-#define NSR_STAT(i, n) do { } while (0)
-#endif
 
 __device__ __forceinline__ bool seq_nonzero(const float4 &v) {
     return ((__float_as_uint(v.x) | __float_as_uint(v.y) | __float_as_uint(v.z) | __float_as_uint(v.w)) << 1) != 0u;
@@ -51,7 +46,13 @@ struct LatGeom {
     uint8_t S[16];          // corners per axis
     uint8_t shift[16];      // the level's lattice is anchored at the origin of the 2^shift-block group the walk is in
 };
-constexpr int LAT_MAX_SLOTS = 1024;                  // float4 slots per wave (16 KB)
+#ifndef NSR_TS_THREADS
+#define NSR_TS_THREADS 256        /* measured on the bench frame: 64 -> 35.6 ms, 128 -> 30.6, 256 -> 29.4 (A + B) */
+#endif
+// float4 slots per wave, from the 64 KB of LDS a workgroup may ask for: level table + per wave (256 B + 16 B per slot), the
+// slot count rounded up to 64 (4 waves: 960).  nsr_table_scatter_supported() and the launch share THIS bound, so a grid is
+// rejected before anything is launched or never (round 2 rejected totals of 961..1024 after the MLP backward had run)
+constexpr int LAT_MAX_SLOTS = (int)(((65536 - 16 * sizeof(NsrLevel)) / (NSR_TS_THREADS / 64) - 256) / 16 / 64 * 64);
 constexpr int LAT_KEY_BITS = 10;                     // must match nsr_sample_order's quantisation
 constexpr uint32_t LAT_NONE = 0xFFFFFFFFu;
 struct LatState {
@@ -90,7 +91,7 @@ static bool lat_geometry(const NsrLevel *lv, LatGeom &g) {
         g.base[l] = (uint16_t)total;
         total += S * S * S;
     }
-    return total <= (uint32_t)LAT_MAX_SLOTS;
+    return ((total + 63u) & ~63u) <= (uint32_t)LAT_MAX_SLOTS;
 }
 
 // Flushes level l's lattice, anchored at cell (b0, b1, b2) -- wave-uniform arguments -- and clears it.
@@ -109,7 +110,6 @@ __device__ __forceinline__ void lat_flush_level(float4 *__restrict__ lat4, uint3
     const float *lf = reinterpret_cast<const float *>(lat4);
 #pragma unroll
     for (int k0 = 0; k0 < NC; k0 += 64) {
-        NSR_STAT(2, 1);
         const int k = k0 + lane;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (k < NC) v = lat4[k];
@@ -157,7 +157,6 @@ __device__ __forceinline__ void lat_flush_dispatch(float4 *__restrict__ lat, int
     const uint32_t o1 = (uint32_t)__builtin_amdgcn_readlane((int)st.b1, fl * 4);
     const uint32_t o2 = (uint32_t)__builtin_amdgcn_readlane((int)st.b2, fl * 4);
     const NsrLevel flv = lds_lv[fl];
-    NSR_STAT(1, 1);
     float4 *lf = lat + (flv.pad_ >> 8);
     uint32_t *rows = reinterpret_cast<uint32_t *>(lat) - 64;                  // 64-entry row scratch in front of the lattices
     switch (flv.pad_ & 0xFu) {

@@ -23,7 +23,10 @@ class GraphedRenderStep:
     Gradients accumulate into model.arena.grad exactly as in eager mode."""
 
     def __init__(self, renderer: Renderer, n_rays: int, loss_fn: Callable[[Dict[str, torch.Tensor], torch.Tensor], torch.Tensor],
-                 warmup: int = 2):
+                 warmup: int = 2, dense: bool = False):
+        # dense: the pixel sets are patches / crops / whole frames (neighbouring pixels): Renderer._use_spatial_order then picks
+        # the spatial sample order + lattice scatter from 16 384 rays on, inside the graph like everything else
+        self.dense = dense
         # Occupancy updates keep their schedule (every cfg.update_iter steps, renderer.py:206-207) but run BETWEEN replays:
         # the full / partial update have different launch shapes, and the per-step counter ring of the eager path
         # changes its pointer every step.  The device-side update (nsr_occ_*) needs no host read, so it costs no bubble.
@@ -42,7 +45,7 @@ class GraphedRenderStep:
         keep = self.r.update_occ
         self.r.update_occ = False          # inside the graph: fixed launch sequence, a private device-side counter
         try:
-            out = self.r.render(self.pose, None, training=True, pix_subset=self.pix)
+            out = self.r.render(self.pose, None, training=True, pix_subset=self.pix, dense=self.dense)
         finally:
             self.r.update_occ = keep
         loss = self.loss_fn(out, self.pix)
@@ -99,18 +102,17 @@ class GraphedRenderStep:
 
 
 class GraphedPatchBackward:
-    """One patch of the deferred back-propagation (trainers/style.py:189-198) as TWO graphs with the sample sort between them:
-    render `n_rays` pixels of a frame with autograd and back-propagate a given d loss / d rgb into model.arena.grad.
+    """One patch of the deferred back-propagation (trainers/style.py:189-198) as ONE graph: render `n_rays` pixels of a frame
+    with autograd and back-propagate a given d loss / d rgb into model.arena.grad.
 
         g = GraphedPatchBackward(renderer, n_rays); g(pose, pix, grad)      # pix [n_rays] positions in the frame, grad [n_rays, 3]
 
     A 1008x756 iteration re-renders 24 patches, ~45 launches each plus their host-side bookkeeping: eager, the GPU waits for
-    the host between kernels (the kernel-event spans of the patch loop are 40 % longer than the kernels).  Graph 1 = ray
-    generation + march + compaction; then, for dense patches, the spatial order of the samples is computed EAGERLY (rocPRIM's
-    radix sort does not survive hipGraph replay, Renderer._use_spatial_order) into a static permutation buffer; graph 2 =
-    fused field + composite + their backward.  Patches of the same size share the graphs (pose, pixel positions and the
-    gradient are static buffers refilled before a replay).  The renderer must not update its occupancy grid in this stage
-    (StyleTrainer never does)."""
+    the host between kernels (the kernel-event spans of the patch loop are 40 % longer than the kernels).  The graph holds ray
+    generation + march + compaction, the spatial order of the samples (nsr_sample_order is capture-safe since round 3: its
+    own radix sort, every counter reset by a kernel of the call) and the fused field + composite + their backward.  Patches of
+    the same size share the graph (pose, pixel positions and the gradient are static buffers refilled before a replay).  The
+    renderer must not update its occupancy grid in this stage (StyleTrainer never does)."""
 
     def __init__(self, renderer: Renderer, n_rays: int, dense: bool = True, warmup: int = 1):
         self.r = renderer
@@ -119,31 +121,25 @@ class GraphedPatchBackward:
         self.pose[:3, :3] = torch.eye(3, device=dev)
         self.pix = torch.arange(n_rays, dtype=torch.int64, device=dev)
         self.grad = torch.zeros(n_rays, 3, dtype=torch.float32, device=dev)
-        self.sorted = renderer._use_spatial_order(n_rays, dense)
-        self.perm = torch.empty(renderer.sample_capacity(n_rays), dtype=torch.int32, device=dev) if self.sorted else None
-        self.mt = None
-        self.g_march = self.g_shade = None
+        self.dense = dense
+        self.graph = None
+        self.counter = None
         self._warmup = warmup
 
-    def _march(self):
+    def _body(self):
         from .rays import generate_rays
         r = self.r
         keep = r.update_occ
         r.update_occ = False               # a private device-side counter, no step bookkeeping inside the graph
         try:
             rays, _ = generate_rays(self.pose, r.intr, None, camera_flip=r.cfg.flip_camera, pix_subset=self.pix, device=r.device)
-            self.mt = r.march_train(rays)
+            mt = r.march_train(rays)
         finally:
             r.update_occ = keep
-
-    def _order(self):
-        if self.sorted:
-            mt = self.mt
-            self.r.model.sample_order(mt['xyzs'], mt['counter'], self.r._sort_prefix(mt['M'], mt['counter']), out=self.perm)
-
-    def _shade(self):
-        image, _, _ = self.r.shade_train(self.mt, self.perm)
+        perm = r.model.sample_order(mt['xyzs'], mt['counter']) if r._use_spatial_order(mt['N'], self.dense) else None
+        image, _, _ = r.shade_train(mt, perm)
         image.backward(self.grad)
+        return mt['counter']
 
     def capture(self):
         """The static buffers must hold a real patch: the warm-up passes run on them, and their gradient is removed again."""
@@ -156,17 +152,11 @@ class GraphedPatchBackward:
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
             for _ in range(self._warmup):
-                self._march()
-                self._order()
-                self._shade()
+                self._body()
         torch.cuda.current_stream().wait_stream(s)
-        self.g_march = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.g_march):
-            self._march()
-        # graph 2 reads graph 1's outputs (kept alive by self.mt, so their memory stays reserved for graph 1) and self.perm
-        self.g_shade = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.g_shade):
-            self._shade()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.counter = self._body()
         model.arena.grad.copy_(saved)
         return self
 
@@ -174,12 +164,10 @@ class GraphedPatchBackward:
         self.pose.copy_(pose)
         self.pix.copy_(pix)
         self.grad.copy_(grad)
-        if self.g_march is None:
+        if self.graph is None:
             self.capture()
         m = self.r.model
         if m.table_dtype == torch.float16 and m._half_version != m.arena._version:
             m._gather_tables()
-        self.g_march.replay()
-        self._order()
-        self.g_shade.replay()
-        self.r._last_counter = self.mt['counter']
+        self.graph.replay()
+        self.r._last_counter = self.counter

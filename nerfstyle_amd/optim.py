@@ -46,45 +46,95 @@ class FusedAdam:
     def zero_grad(self, set_to_none=False):
         self.model._ensure_grad().zero_()
 
-    @torch.no_grad()
-    def step(self, grad_scale=1.0):
-        """One update; gradients are zeroed on the way out.  grad_scale: the loss scale the
-        gradients carry (GradScaler): they are multiplied by 1/grad_scale inside the kernel."""
+    def _regions(self):
+        """[(offset, n, elem_mask4, half_n)] of the arena the optimiser trains, merged where contiguous: everything trained
+        (the reconstruction stage) is ONE launch over the whole arena, colour table only (stylisation) is one over the tables."""
         m = self.model
-        g = m._ensure_grad()
-        self.step_count += 1
-        lr = self.param_groups[0]['lr']
-        decay = 0.0
-        if self.ema is not None:
-            # torch_ema: decay = min(decay, (1 + n) / (10 + n)) with n counted before the update
-            self.ema_updates += 1
-            decay = min(self.ema_decay, (1 + self.ema_updates) / (10 + self.ema_updates))
-        a = m.arena.detach()
-        half = m.half_tables() if m.table_dtype == torch.float16 else None
-
-        def run(off, n, mask, half_ptr):
-            ptr = lambda t: t.data_ptr() + off * 4
-            L.check(L.lib().nsr_adam_step(
-                ptr(a), ptr(g), ptr(self.exp_avg), ptr(self.exp_avg_sq), ptr(self.ema) if self.ema is not None else None,
-                half_ptr, n, float(lr), float(self.betas[0]), float(self.betas[1]), float(self.eps),
-                float(1.0 / grad_scale), float(decay), self.step_count, mask, L.stream()), 'adam_step')
-
+        all_nets = len(self.nets) == len(MLP_LAYOUT)
+        if self.table_mask == 0xF and all_nets:
+            return [(0, m.arena.numel(), 0xF, m.table_elems)]
+        out = []
         if self.table_mask:
-            run(0, m.table_elems, self.table_mask, half.data_ptr() if half is not None else None)
+            out.append((0, m.table_elems, self.table_mask, m.table_elems))
+        if all_nets:
+            out.append((m.table_elems, m.arena.numel() - m.table_elems, 0xF, 0))
         else:
+            out += [(m.table_elems + off, n, 0xF, 0) for (off, n) in self.nets]
+        return out
+
+    def _zero_untrained(self, g):
+        m = self.model
+        if not self.table_mask:
             g[:m.table_elems].zero_()
-        trained = set()
-        for (off, n) in self.nets:
-            run(m.table_elems + off, n, 0xF, None)
-            trained.add(off)
+        trained = {off for (off, n) in self.nets}
         for (name, off, n) in MLP_LAYOUT:
             if off not in trained:
                 g[m.table_elems + off: m.table_elems + off + n].zero_()
+
+    def _ema_decay_now(self):
+        if self.ema is None:
+            return 0.0
+        # torch_ema: decay = min(decay, (1 + n) / (10 + n)) with n counted before the update
+        self.ema_updates += 1
+        return min(self.ema_decay, (1 + self.ema_updates) / (10 + self.ema_updates))
+
+    @torch.no_grad()
+    def step(self, grad_scale=1.0, scaler=None, lr_decay_steps=0.0):
+        """One update; gradients are zeroed on the way out.
+        scaler=None: host-side scalars -- grad_scale is the loss scale the gradients carry (multiplied by 1/grad_scale inside
+        the kernel), lr = param_groups[0]['lr'], the step count lives here.
+        scaler=LossScaler: GradScaler semantics ON THE DEVICE (nsr_grad_check -> nsr_scaler_update -> nsr_adam_step_scaled):
+        inf/nan check over the trained regions, skip + back-off or step + growth, the step count, lr = param_groups[0]
+        ['initial_lr'] * 0.1^(steps / lr_decay_steps) (trainers/base.py:223-226: LambdaLR, advanced only on steps that
+        were not skipped) and the bias corrections all stay in `scaler.state`; nothing is read back."""
+        m = self.model
+        g = m._ensure_grad()
+        a = m.arena.detach()
+        half = m.half_tables() if m.table_dtype == torch.float16 else None
+        decay = self._ema_decay_now()
+        ptr = lambda t, off: t.data_ptr() + off * 4
+        regions = self._regions()
+        if scaler is None:
+            self.step_count += 1
+            lr = self.param_groups[0]['lr']
+            for (off, n, mask, half_n) in regions:
+                # the host-scalar entry point has no half_n: a whole-arena region is split at the table end
+                parts = [(off, n)] if half_n in (0, n) or half is None else [(off, half_n), (off + half_n, n - half_n)]
+                for (o, k) in parts:
+                    L.check(L.lib().nsr_adam_step(
+                        ptr(a, o), ptr(g, o), ptr(self.exp_avg, o), ptr(self.exp_avg_sq, o),
+                        ptr(self.ema, o) if self.ema is not None else None,
+                        half.data_ptr() if (half is not None and o == 0 and half_n) else None, k, float(lr), float(self.betas[0]),
+                        float(self.betas[1]), float(self.eps), float(1.0 / grad_scale), float(decay), self.step_count, mask,
+                        L.stream()), 'adam_step')
+        else:
+            st = scaler.state_on(a.device)
+            for (off, n, mask, half_n) in regions:
+                L.check(L.lib().nsr_grad_check(ptr(g, off), n, mask, L.p(st), L.stream()), 'grad_check')
+            L.check(L.lib().nsr_scaler_update(L.p(st), float(self.param_groups[0]['initial_lr']), float(lr_decay_steps),
+                                              float(self.betas[0]), float(self.betas[1]), float(scaler.growth_factor),
+                                              float(scaler.backoff_factor), int(scaler.growth_interval), int(scaler.enabled),
+                                              L.stream()), 'scaler_update')
+            for (off, n, mask, half_n) in regions:
+                L.check(L.lib().nsr_adam_step_scaled(
+                    ptr(a, off), ptr(g, off), ptr(self.exp_avg, off), ptr(self.exp_avg_sq, off),
+                    ptr(self.ema, off) if self.ema is not None else None,
+                    half.data_ptr() if (half is not None and off == 0 and half_n) else None, n, half_n if half is not None else 0,
+                    float(self.betas[0]), float(self.betas[1]), float(self.eps), float(decay), mask, L.p(st), L.stream()),
+                    'adam_step_scaled')
+            self._scaler = scaler
+        self._zero_untrained(g)
         if half is not None and self.table_mask:
             m.mark_half_synced()
 
+    @property
+    def steps_taken(self):
+        """Optimiser steps really taken (host read when a device-side scaler keeps the count)."""
+        sc = getattr(self, '_scaler', None)
+        return int(sc.state[3].item()) if sc is not None and sc.state is not None else self.step_count
+
     def state_dict(self):
-        return {'step': self.step_count, 'exp_avg': self.exp_avg, 'exp_avg_sq': self.exp_avg_sq, 'ema': self.ema,
+        return {'step': self.steps_taken, 'exp_avg': self.exp_avg, 'exp_avg_sq': self.exp_avg_sq, 'ema': self.ema,
                 'ema_updates': self.ema_updates, 'lr': self.param_groups[0]['lr']}
 
     def load_state_dict(self, sd):
@@ -103,52 +153,67 @@ def exp_lr(initial_lr, it, decay_steps):
 
 
 class LossScaler:
-    """Dynamic loss scaling with torch.cuda.amp.GradScaler's policy (trainers/base.py:228,420-425:
-    init 65536, x2 after 2000 clean steps, x0.5 and skip the step on inf/nan), for the f16 MFMA path:
-    with f16 operands the gradients of a mean-over-rays loss underflow unscaled (the reference trains
-    tcnn's fp16 networks under GradScaler for the same reason).  bf16 compute needs no scaling.
+    """torch.cuda.amp.GradScaler's policy (trainers/base.py:228,420-425: init 65536, x2 after 2000 clean steps, x0.5 and skip
+    the step on inf/nan) with every piece of state ON THE DEVICE (`state`: int32[16], layout in include/nsr.h): the scale the
+    loss is multiplied by is a device scalar, the inf/nan check is one streaming pass over the trained gradient regions, the
+    skip decision is taken by the optimiser kernel itself.  No `.item()`, legal under hipGraph capture.  With f16 operands
+    the gradients of a mean-over-rays loss underflow unscaled (the reference trains tcnn's fp16 networks under GradScaler for
+    the same reason); bf16 compute needs no scaling (enabled=False: scale 1, never skips).
 
-        loss = scaler.scale(loss); loss.backward(); stepped = scaler.step(opt)
-
-    The inf/nan check is one reduction over the flat gradient arena and one host read per step."""
+        loss = scaler.scale(loss); loss.backward(); scaler.step(opt)          # opt: FusedAdam
+    """
 
     def __init__(self, init_scale=65536.0, growth_factor=2.0, backoff_factor=0.5, growth_interval=2000, enabled=True):
-        self.scale_value = float(init_scale) if enabled else 1.0
+        self.init_scale = float(init_scale) if enabled else 1.0
         self.growth_factor, self.backoff_factor, self.growth_interval = growth_factor, backoff_factor, growth_interval
         self.enabled = enabled
-        self._good_steps = 0
+        self.state = None
+        # host-side values, uploaded when the device is known (and the source of state_dict() until then)
+        self._pending = {'scale': self.init_scale, '_growth_tracker': 0, 'steps': 0, 'skipped': 0}
+
+    def state_on(self, device):
+        if self.state is None or self.state.device != device:
+            host = torch.zeros(16, dtype=torch.int32)
+            vals = self._pending if self._pending is not None else self._read_back()
+            host[0:1].view(torch.float32)[0] = float(vals['scale'])
+            host[1], host[3], host[4] = int(vals['_growth_tracker']), int(vals['steps']), int(vals['skipped'])
+            self.state = host.to(device)
+            self._pending = None
+        return self.state
+
+    def _read_back(self):
+        st = self.state.cpu()
+        return {'scale': float(st[0:1].view(torch.float32)[0]), '_growth_tracker': int(st[1]), 'steps': int(st[3]), 'skipped': int(st[4])}
+
+    def scale_tensor(self, device):
+        """0-dim float32 view of the device-side scale (what `scale(loss)` multiplies by)."""
+        return self.state_on(device)[0:1].view(torch.float32)[0]
 
     def scale(self, loss):
-        return loss * self.scale_value
+        return loss * self.scale_tensor(loss.device)
 
     def get_scale(self):
-        return self.scale_value
+        """Host read (diagnostics / checkpoints only)."""
+        return float(self.state[0:1].view(torch.float32)[0].item()) if self.state is not None else float(self._pending['scale'])
+
+    def steps_skipped(self):
+        return int(self.state[4].item()) if self.state is not None else 0
 
     def state_dict(self):
-        """torch.cuda.amp.GradScaler.state_dict's keys (trainers/base.py:28, SD_SAVE_KEYS 'scaler')"""
-        return {'scale': float(self.scale_value), 'growth_factor': self.growth_factor, 'backoff_factor': self.backoff_factor,
-                'growth_interval': self.growth_interval, '_growth_tracker': int(self._good_steps)}
+        """torch.cuda.amp.GradScaler.state_dict's keys (trainers/base.py:28, SD_SAVE_KEYS 'scaler') + the step counters"""
+        v = self._read_back() if self.state is not None else dict(self._pending)
+        v.update({'growth_factor': self.growth_factor, 'backoff_factor': self.backoff_factor, 'growth_interval': self.growth_interval})
+        return v
 
     def load_state_dict(self, sd):
-        self.scale_value = float(sd['scale'])
         self.growth_factor, self.backoff_factor = sd['growth_factor'], sd['backoff_factor']
         self.growth_interval = sd['growth_interval']
-        self._good_steps = int(sd.get('_growth_tracker', 0))
+        self._pending = {'scale': float(sd['scale']), '_growth_tracker': int(sd.get('_growth_tracker', 0)),
+                         'steps': int(sd.get('steps', 0)), 'skipped': int(sd.get('skipped', 0))}
+        dev = self.state.device if self.state is not None else None
+        self.state = None
+        if dev is not None:
+            self.state_on(dev)
 
-    def step(self, opt: FusedAdam) -> bool:
-        if not self.enabled:
-            opt.step()
-            return True
-        g = opt.model._ensure_grad()
-        finite = bool(torch.isfinite(g.abs().max()).item())
-        if finite:
-            opt.step(grad_scale=self.scale_value)
-            self._good_steps += 1
-            if self._good_steps >= self.growth_interval:
-                self.scale_value *= self.growth_factor
-                self._good_steps = 0
-            return True
-        g.zero_()
-        self.scale_value *= self.backoff_factor
-        self._good_steps = 0
-        return False
+    def step(self, opt: FusedAdam, lr_decay_steps=0.0) -> None:
+        opt.step(scaler=self, lr_decay_steps=lr_decay_steps)

@@ -80,21 +80,28 @@ def broadcast_(flat: torch.Tensor, src=0):
     return flat
 
 
-def sync_gradients(model, only_color_table=False):
-    """All-reduce (sum) of the gradient arena: ONE flat 100.9 MB message.
-    only_color_table: the stylisation stage trains `x_color_embedder` alone (trainers/style.py:25).  Its gradient is
-    every second float2 of the interleaved table rows: it is packed into a contiguous 50.4 MB buffer, reduced and
-    unpacked -- half the bytes on the links for two extra streaming passes; the other gradients are left as they are
-    (the optimiser's element mask ignores and zeroes them)."""
+def sync_gradients(model, optimizer=None, only_color_table=None):
+    """All-reduce (sum) of the gradient arena: ONE flat 100.9 MB message -- or, when `optimizer` (a FusedAdam) trains one
+    hash table only and no MLP (the stylisation stage: `x_color_embedder` alone, trainers/style.py:25), that table's
+    gradient alone: every second float2 of the interleaved rows, packed into a contiguous 50.4 MB buffer, reduced and
+    unpacked -- half the bytes on the links for two extra streaming passes.  What is reduced is derived from what the
+    optimiser trains (table_mask / nets), so every region it steps -- and every region its inf/nan check looks at -- is
+    identical on all ranks; untrained regions stay rank-local (the optimiser ignores and zeroes them).
+    only_color_table (legacy switch) forces the packed colour path when True."""
     g = model._ensure_grad()
     if world_size() == 1:
         return g
-    if not only_color_table:
+    half = None
+    if only_color_table:
+        half = 1
+    elif only_color_table is None and optimizer is not None and not optimizer.nets and optimizer.table_mask in (0x3, 0xC):
+        half = 0 if optimizer.table_mask == 0x3 else 1
+    if half is None:
         return all_reduce_sum_(g)
-    colour = g[:model.table_elems].view(model.rows, 2, 2)[:, 1, :]
-    packed = colour.contiguous()
+    part = g[:model.table_elems].view(model.rows, 2, 2)[:, half, :]
+    packed = part.contiguous()
     all_reduce_sum_(packed)
-    colour.copy_(packed)
+    part.copy_(packed)
     return g
 
 

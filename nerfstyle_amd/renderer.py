@@ -46,8 +46,6 @@ class Renderer(torch.nn.Module):
         self.sort_samples = 'auto'
         self.sort_min_rays = 140000      # any batch of at least this many rays ...
         self.sort_min_dense_rays = 16384  # ... or a DENSE pixel set (full frame / patch / crop: neighbouring pixels) of this many
-        self.sort_prefix_hint = None     # estimate of the emitted sample count (host int) so a capacity buffer is not sorted whole;
-        self._count_probe = None         # None = maintained here from the previous calls' counts, read back without blocking
         self._pinned_bitfield = None
         self.aabb = torch.tensor([-bound, -bound, -bound, bound, bound, bound], dtype=torch.float32)
         self.cascade = 1 + ceil(log2(bound))
@@ -206,7 +204,7 @@ class Renderer(torch.nn.Module):
         mt = self.march_train(rays)
         perm = None
         if torch.is_grad_enabled() and self._use_spatial_order(mt['N'], bool(kwargs.get('dense', False))):
-            perm = self.model.sample_order(mt['xyzs'], mt['counter'], self._sort_prefix(mt['M'], mt['counter']))
+            perm = self.model.sample_order(mt['xyzs'], mt['counter'])
         return self.shade_train(mt, perm)
 
     def march_train(self, rays: RayBatch) -> dict:
@@ -243,44 +241,9 @@ class Renderer(torch.nn.Module):
     def _use_spatial_order(self, n_rays: int, dense: bool) -> bool:
         if getattr(self.model, '_spatial_scatter_unsupported', False):
             return False                 # learnt from a backward that fell back (style_nerf._field.backward)
-        if torch.cuda.is_current_stream_capturing():
-            # rocPRIM's radix sort does not survive hipGraph replay on ROCm 7.2 / MI355X: captured alone, the first replay
-            # is correct and the second one faults inside radix_sort_onesweep_iteration, also when its temporary storage
-            # is cleared by a kernel first (tools/exp_patch_graph.py stage 1).  A captured step therefore never sorts:
-            # it uses the ray-order run tracker, or gets its permutation from an eager sort between two graphs
-            # (graph.GraphedPatchBackward).
-            return False
         if self.sort_samples != 'auto':
             return bool(self.sort_samples)
         return n_rays >= self.sort_min_rays or (dense and n_rays >= self.sort_min_dense_rays)
-
-    def _sort_prefix(self, M: int, counter: torch.Tensor) -> int:
-        """How many leading slots of the capacity-sized sample buffer take part in the sort: an estimate of the emitted count
-        (any value is correct, see nsr_sample_order).  The count of an earlier call is copied to pinned host memory
-        asynchronously and picked up once its event has completed -- the step never waits for it."""
-        if self.sort_prefix_hint is not None:
-            return min(int(self.sort_prefix_hint), M)
-        if torch.cuda.is_current_stream_capturing():
-            return M                     # no event queries / host copies inside a graph capture
-        est = M
-        probe = self._count_probe
-        if probe is not None:
-            host, ev, last = probe
-            if ev is not None and ev.query():
-                last = int(host[0])
-                ev = None
-            if last is not None:
-                est = min(M, int(last * 1.15) + 65536)
-            self._count_probe = (host, ev, last)
-        if self._count_probe is None or self._count_probe[1] is None:
-            host = self._count_probe[0] if self._count_probe is not None else torch.zeros(2, dtype=torch.int32).pin_memory()
-            last = self._count_probe[2] if self._count_probe is not None else None
-            # enqueue AFTER the march of this call has written the counter: the caller passes the live counter tensor
-            host.copy_(counter, non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record()
-            self._count_probe = (host, ev, last)
-        return est
 
     def last_call_overflowed(self) -> torch.Tensor:
         """Device-side flag (0-dim bool tensor, no host sync) of the last render_train call: the march emitted
@@ -361,57 +324,10 @@ class Renderer(torch.nn.Module):
         depth = torch.clamp(depth - nears, min=0) / (fars - nears)
         return image, depth, classes
 
-    def prefetch_train(self, pose, pix_subset, dense: bool = False) -> bool:
-        """Runs the parameter-independent front of the NEXT training render -- ray generation, occupancy march, compaction and
-        the spatial order of the samples -- on a side stream, so that it overlaps whatever the caller enqueues next on the
-        current stream (the backward of the step in flight: the march is latency-bound, the backward leaves issue slots and
-        registers free for part of its run; 38.0 -> 36.8 ms per full-frame step).  The next `render(pose, training=True,
-        pix_subset=pix_subset)` with the SAME two tensor objects picks the result up; anything else discards it.
-        Nothing is prefetched (returns False) when that render will begin with an occupancy update: the update reads the
-        parameters the optimiser step in between is about to change."""
-        self._prefetched = None
-        if not torch.is_grad_enabled() or self._use_precrop:
-            return False
-        if self.update_occ and (self.local_step % self.cfg.update_iter == 0):
-            return False
-        main = torch.cuda.current_stream(self.device)
-        if getattr(self, '_side_stream', None) is None:
-            self._side_stream = torch.cuda.Stream(device=self.device)
-        side = self._side_stream
-        side.wait_stream(main)                      # pose / pix_subset were produced on the current stream
-        with torch.cuda.stream(side):
-            rays, _ = generate_rays(pose, self.intr, None, camera_flip=self.cfg.flip_camera, pix_subset=pix_subset, device=self.device)
-            mt = self.march_train(rays)
-            perm = None
-            if self._use_spatial_order(mt['N'], dense):
-                perm = self.model.sample_order(mt['xyzs'], mt['counter'], self._sort_prefix(mt['M'], mt['counter']))
-            done = torch.cuda.Event()
-            done.record(side)
-        self._prefetched = (pose, pix_subset, dense, mt, perm, done)
-        return True
-
-    def _take_prefetched(self, pose, pix_subset, dense):
-        pf, self._prefetched = getattr(self, '_prefetched', None), None
-        if pf is None or pf[0] is not pose or pf[1] is not pix_subset or pf[2] != dense:
-            return None
-        _, _, _, mt, perm, done = pf
-        main = torch.cuda.current_stream(self.device)
-        main.wait_event(done)
-        for t in list(mt.values()) + [perm]:        # allocated on the side stream, consumed (and freed) on this one
-            if torch.is_tensor(t):
-                t.record_stream(main)
-        return mt, perm
-
     def render(self, pose, image=None, patch: Optional[Box2D] = None, num_rays: Optional[int] = None,
                training: bool = False, pix_subset=None, dense: Optional[bool] = None) -> Dict[str, torch.Tensor]:
         """renderer.py:295-313.  `dense` overrides the guess below for callers that pass a patch as `pix_subset`."""
         output = {}
-        if training and image is None and patch is None and num_rays is None and getattr(self, '_prefetched', None) is not None:
-            pf = self._take_prefetched(pose, pix_subset, bool(dense))
-            if pf is not None:
-                output['target'] = None
-                output['rgb_map'], output['trans_map'], output['classes'] = self.shade_train(*pf)
-                return output
         precrop_frac = self.precrop_frac if self._use_precrop else 1.
         rays, output['target'] = generate_rays(pose, self.intr, image, patch=patch, precrop=precrop_frac, bsize=num_rays,
                                                camera_flip=self.cfg.flip_camera, pix_subset=pix_subset,

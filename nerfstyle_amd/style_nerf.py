@@ -352,20 +352,9 @@ class StyleTCNerf(nn.Module):
         M = xyzs.shape[0]
         dev = xyzs.device
         need = (int(L.lib().nsr_sample_order_workspace_bytes(M)) + 3) // 4 + 64
-        if torch.cuda.is_current_stream_capturing():
-            # a captured launch bakes its pointers in: the workspace must belong to the graph's own pool, not to a cache
-            # on the model that a later call with another M replaces
-            ws = torch.empty(need, dtype=torch.int32, device=dev)
-        else:
-            # one workspace per stream: Renderer.prefetch_train sorts on a side stream, and a sort on the current stream may
-            # run at the same time (two sorts sharing rocPRIM's temporary storage corrupt each other: a memory fault)
-            if not isinstance(getattr(self, '_order_ws', None), dict):
-                self._order_ws = {}
-            key = torch.cuda.current_stream(dev).cuda_stream
-            ws = self._order_ws.get(key)
-            if ws is None or ws.device != dev or ws.numel() < need:
-                self._order_ws.pop(key, None)
-                ws = self._order_ws[key] = torch.empty(need, dtype=torch.int32, device=dev)
+        # a temporary of torch's stream-ordered caching allocator: no hipMalloc in the steady state, correct on any stream,
+        # and under capture it belongs to the graph's own pool (a captured launch bakes its pointers in)
+        ws = torch.empty(need, dtype=torch.int32, device=dev)
         ws_ptr = (ws.data_ptr() + 255) & ~255
         perm = torch.empty(M, dtype=torch.int32, device=dev) if out is None else out
         assert perm.dtype == torch.int32 and perm.numel() == M and perm.is_contiguous() and perm.device == dev

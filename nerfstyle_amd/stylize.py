@@ -111,12 +111,14 @@ def _all_gather_ragged(chunks, part):
         c.copy_(b[:c.shape[0]])
 
 
-def deferred_backprop_step(renderer, pose, image_loss: Callable, patch_size: int = 200, loss_scale: float = 1.0, rank: int = 0,
-                           world: int = 1, only_color_table: bool = True, with_classes: bool = False,
+def deferred_backprop_step(renderer, pose, image_loss: Callable, patch_size: int = 200, loss_scale=1.0, rank: int = 0,
+                           world: int = 1, optimizer=None, with_classes: bool = False,
                            patch_graphs: Optional[dict] = None):
     """One stylisation iteration up to (not including) the optimiser step.  `image_loss` maps rgb [H, W, 3]
     (requires_grad) -- and, with_classes, the class logits [H, W, nc] of the same pass -- to a scalar.
     Gradients accumulate into model.arena.grad.  Returns (loss value, rgb_map of pass 1).
+    loss_scale: float or 0-dim device tensor (optim.LossScaler.scale_tensor).  optimizer: the FusedAdam that will step; at
+    world > 1 the all-reduce covers exactly what it trains (parallel.sync_gradients) -- None reduces the whole arena.
     patch_graphs: a dict the caller keeps across iterations; when given, pass 2 replays one hipGraph per patch shape
     (graph.GraphedPatchBackward) instead of launching every patch's kernels from the host."""
     W, H = renderer.intr.size()
@@ -146,5 +148,5 @@ def deferred_backprop_step(renderer, pose, image_loss: Callable, patch_size: int
             patch_graphs[key] = GraphedPatchBackward(renderer, box.w * box.h, dense=True)
         patch_graphs[key](torch.as_tensor(pose, dtype=torch.float32, device=renderer.device), pix, g)
     if world > 1:
-        P.sync_gradients(renderer.model, only_color_table=only_color_table)
+        P.sync_gradients(renderer.model, optimizer=optimizer)
     return loss.detach(), rgb.detach()

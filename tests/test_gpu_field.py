@@ -403,6 +403,36 @@ def test_sample_order_and_sorted_walk_equal_buffer_order(O, dev, dt, table_dtype
     assert torch.equal(s_only[:cnt], s0)
 
 
+def test_sample_order_captured_alone_replays_equal_eager(O, dev):
+    """nsr_sample_order is capture-safe (round 3: its own LSD radix sort; round 2's rocPRIM call reset a tile counter with a
+    stream-less hipMemset per pass and faulted on the SECOND replay): captured alone, four replays -- with a different
+    device-side count before the last one -- equal the eager permutation."""
+    m, _ = _field_pair(dev, 'f16', None)
+    M = 40000 * 64
+    g = torch.Generator(device=dev)
+    g.manual_seed(11)
+    xyzs = (torch.rand(M, 3, device=dev, generator=g) * 3.6 - 1.8).contiguous()
+    cnt = torch.tensor([M - 1000, 0], dtype=torch.int32, device=dev)
+    p_eager = m.sample_order(xyzs, cnt).clone()
+    side = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        m.sample_order(xyzs, cnt)
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        p_graph = m.sample_order(xyzs, cnt)
+    for _ in range(3):
+        p_graph.zero_()
+        graph.replay()
+        assert torch.equal(p_graph, p_eager)
+    cnt.copy_(torch.tensor([M // 3, 0], dtype=torch.int32))
+    p_small = m.sample_order(xyzs, cnt).clone()
+    graph.replay()
+    assert torch.equal(p_graph, p_small) and not torch.equal(p_small, p_eager)
+    assert torch.equal(p_small[M // 3:], torch.arange(M // 3, M, dtype=torch.int32, device=dev))
+
+
 @pytest.mark.parametrize('nc', [1, 13])
 def test_field_other_class_counts(O, dev, nc):
     """C_ch = 3 + nc other than the vectorised 8-channel case: 4 channels (nc = 1) and the largest the
@@ -457,3 +487,36 @@ def test_spatial_scatter_falls_back_on_unsupported_grid(O, dev):
     g1 = run(m.sample_order(pts))
     assert m._spatial_scatter_unsupported
     assert float(g0.abs().sum()) > 0 and rel_l2(g1.cpu().numpy(), g0.cpu().numpy()) < 2e-5
+
+
+@pytest.mark.parametrize('min_res,coeff', [(24, 1280), (48, 1280)])
+def test_spatial_scatter_near_lds_limit_counts_mlp_gradient_once(O, dev, min_res, coeff):
+    """Grids whose lattices need 961..1024 float4 slots per wave: round 2 accepted them in nsr_table_scatter_supported and
+    rejected them (64 KB of LDS) AFTER the MLP backward kernel had accumulated its weight gradient, and the host re-issued the
+    whole backward -- MLP gradients counted twice.  The LDS bound is now part of the support test: whichever way such a grid
+    goes (supported, or rejected before any launch), the gradient equals the call without perm."""
+    from nerfstyle_amd.common import BBox
+    from nerfstyle_amd.config import NetworkConfig, PosEncConfig
+    from nerfstyle_amd.style_nerf import StyleTCNerf
+    m = StyleTCNerf(NetworkConfig(pos_enc=PosEncConfig(min_res=min_res, max_res_coeff=coeff)), BBox.from_radius(2.0), 5,
+                    enc_dtype=torch.float32, use_dir=False).to(dev)
+    with torch.no_grad():
+        m.arena[:m.table_elems].uniform_(-0.5, 0.5)
+        m.arena.add_(0)
+    rng = np.random.default_rng(5)
+    pts = T((rng.random((6000, 3)) * 4 - 2).astype(np.float32), dev)
+    gs = T((rng.standard_normal(6000) * 1e-2).astype(np.float32), dev)
+    gr = T(rng.standard_normal((6000, 8)).astype(np.float32), dev)
+
+    def run(p):
+        m.arena.grad = None
+        m.grad_arena = None
+        sig, rgb = m.field(pts, False, perm=p)
+        torch.autograd.backward([sig, rgb], [gs, gr])
+        return m.arena.grad.detach().clone()
+    g0 = run(None)
+    g1 = run(m.sample_order(pts))
+    mlp0, mlp1 = g0[m.table_elems:].cpu().numpy(), g1[m.table_elems:].cpu().numpy()
+    assert float(np.abs(mlp0).sum()) > 0 and rel_l2(mlp1, mlp0) < 2e-5
+    assert rel_l2(g1.cpu().numpy(), g0.cpu().numpy()) < 2e-5
+

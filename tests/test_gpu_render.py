@@ -165,6 +165,80 @@ def test_fused_adam_ema_matches_torch_ema_formula(dev):
     assert torch.equal(m.half_tables(), m.arena.detach()[:m.table_elems].half())
 
 
+@pytest.mark.parametrize('keywords', [None, ['x_color_embedder']])
+def test_device_side_grad_scaler_equals_torch_gradscaler(dev, keywords):
+    """LossScaler + FusedAdam.step(scaler=...) -- inf/nan check, skip, back-off / growth, step count, LambdaLR and bias
+    corrections all on the device (nsr_grad_check / nsr_scaler_update / nsr_adam_step_scaled) -- against
+    torch.cuda.amp.GradScaler + torch.optim.Adam + LambdaLR driven as the reference drives them (trainers/base.py:420-426:
+    scaler.step, scaler.update, scheduler.step only if the scale did not drop, ema.update always) on a sequence of finite /
+    inf / nan gradients, growth_interval 3 so that growth happens too.  With keywords = colour table only, a non-finite value
+    in an UNTRAINED region must not skip the step (the reference's optimiser does not hold those parameters)."""
+    from nerfstyle_amd.common import BBox
+    from nerfstyle_amd.config import NetworkConfig
+    from nerfstyle_amd.optim import FusedAdam, LossScaler
+    from nerfstyle_amd.style_nerf import StyleTCNerf
+    m = StyleTCNerf(NetworkConfig(), BBox.from_radius(2.0), 5, enc_dtype=None, use_dir=False).to(dev)
+    opt = FusedAdam(m, lr=1e-2, betas=(0.9, 0.999), eps=1e-15, keywords=keywords, ema_decay=0.95)
+    sc = LossScaler(init_scale=1024.0, growth_interval=3)
+    decay_steps = 50.0
+    n = m.arena.numel()
+    trained = torch.zeros(n, dtype=torch.bool, device=dev)
+    if keywords is None:
+        trained[:] = True
+    else:
+        trained[:m.table_elems].view(-1, 4)[:, 2:] = True          # interleaved rows: [density 2 | colour 2]
+    pt = torch.nn.Parameter(m.arena.detach().clone())
+    topt = torch.optim.Adam([pt], lr=1e-2, betas=(0.9, 0.999), eps=1e-15)
+    sched = torch.optim.lr_scheduler.LambdaLR(topt, lambda it: 0.1 ** (it / decay_steps))
+    tsc = torch.cuda.amp.GradScaler(init_scale=1024.0, growth_interval=3)
+    tsc.scale(torch.zeros(1, device=dev))                       # lazy initialisation of the scale tensor
+    shadow = pt.detach().clone()
+    g = torch.Generator(device=dev)
+    g.manual_seed(4)
+    bad_trained = int(torch.nonzero(trained)[12345])
+    bad_untrained = int(torch.nonzero(~trained)[777]) if keywords is not None else None
+    #            0     1      2     3     4     5      6     7     8     9
+    kinds = ['ok', 'ok', 'inf', 'ok', 'ok', 'ok', 'nan', 'ok', 'untrained_inf', 'ok', 'ok', 'ok']
+    skipped = 0
+    for it, kind in enumerate(kinds):
+        scale_now = tsc.get_scale()
+        assert sc.get_scale() == scale_now, it
+        grad = torch.randn(n, device=dev, generator=g) * 1e-3 * scale_now
+        if kind == 'inf':
+            grad[bad_trained] = float('inf')
+        elif kind == 'nan':
+            grad[bad_trained] = float('nan')
+        elif kind == 'untrained_inf' and bad_untrained is not None:
+            grad[bad_untrained] = float('-inf')
+        m._ensure_grad().copy_(grad)
+        # the reference's optimiser only holds the trained parameters: their gradients are the only ones it checks / applies
+        pt.grad = torch.where(trained, grad, torch.zeros_like(grad))
+        before = pt.detach().clone()
+        tsc.step(topt)
+        old = tsc.get_scale()
+        tsc.update()
+        if old <= tsc.get_scale():
+            sched.step()
+        else:
+            skipped += 1
+        sc.step(opt, lr_decay_steps=decay_steps)
+        with torch.no_grad():                                    # untrained entries never move in either optimiser
+            pt.copy_(torch.where(trained, pt.detach(), before))
+        n_upd = it + 1
+        d = min(0.95, (1 + n_upd) / (10 + n_upd))
+        shadow.sub_((1.0 - d) * (shadow - pt.detach()))
+        assert float((m.arena.detach() - pt.detach()).abs().max()) < 2e-6, (it, kind)
+        assert float((opt.ema - shadow).abs().max()) < 2e-6, (it, kind)
+        assert float(m.arena.grad.abs().max()) == 0.0, (it, kind)                 # zeroed also on a skipped step
+    assert skipped == 2 and sc.steps_skipped() == 2 and opt.steps_taken == len(kinds) - 2
+    assert sc.get_scale() == tsc.get_scale()
+    st = sc.state_dict()
+    assert st['_growth_tracker'] == int(tsc.state_dict()['_growth_tracker'])
+    assert abs(float(sc.state[12:13].view(torch.float32)[0]) - topt.param_groups[0]['lr'] / (0.1 ** (1 / decay_steps))) < 1e-7 * 1e-2 + 1e-9
+    if m.table_dtype == torch.float16:
+        assert torch.equal(m.half_tables(), m.arena.detach()[:m.table_elems].half())
+
+
 def _occ_renderer(dev, H):
     import nerfstyle_amd.renderer as RM
     from nerfstyle_amd.common import BBox
@@ -535,8 +609,7 @@ def test_reconstruction_training_learns_with_occupancy_updates(O, dev):
         out = r.render(pose, None, training=True, pix_subset=pix)
         loss = torch.mean((out['rgb_map'] - target[pix]) ** 2) + 1e-3 * torch.nn.functional.cross_entropy(out['classes'], tcls[pix])
         scaler.scale(loss).backward()
-        opt.param_groups[0]['lr'] = exp_lr(1e-2, it, 30000)
-        scaler.step(opt)
+        scaler.step(opt, lr_decay_steps=30000)
         if it == 0:
             psnr0 = eval_psnr()
             assert r.local_step == 1 and int(r.density_bitfield.count_nonzero()) > 0      # update_state ran
@@ -729,51 +802,27 @@ def test_style_criterion_autocast_close_to_fp32(dev):
                 assert cos > tol_cos, (amp, cos)
 
 
-def test_prefetched_march_equals_plain_render(O, dev):
-    """Renderer.prefetch_train (march + compaction + sample order of the next render on a side stream) followed by the
-    matching render gives bit-identical outputs and the same gradient as the plain render; a non-matching render discards it;
-    nothing is prefetched in front of an occupancy update."""
+def test_sorts_on_two_streams_do_not_disturb_each_other(O, dev):
+    """Two training renders with the spatial sample order issued back to back on two streams (each sort has its own
+    stream-ordered workspace: no shared scratch, no null-stream memset as with round 2's library sort) give the results of the
+    same renders run one after the other."""
     r, ref, poses, intr, bits = _setup(dev, cap=256)
     m = r.model
     r.sort_samples = True
     g = torch.Generator().manual_seed(9)
     pix = torch.randperm(intr.w * intr.h, generator=g)[:30000].to(dev)
-    pose = torch.tensor(poses[2], device=dev)
-    tgt = torch.rand(30000, 3, generator=g).to(dev)
-
-    def grads(prefetch):
-        m._ensure_grad()
-        m.arena.grad.zero_()
-        if prefetch:
-            assert r.prefetch_train(pose, pix)
-        out = r.render(pose, None, training=True, pix_subset=pix)
-        assert getattr(r, '_prefetched', None) is None
-        torch.mean((out['rgb_map'] - tgt) ** 2).backward()
-        return out['rgb_map'].detach().clone(), out['classes'].detach().clone(), m.arena.grad.clone()
-
-    rgb0, cls0, g0 = grads(False)
-    rgb1, cls1, g1 = grads(True)
-    assert torch.equal(rgb0, rgb1) and torch.equal(cls0, cls1)
-    assert float(g0.abs().sum()) > 0 and rel_l2(g1.cpu().numpy(), g0.cpu().numpy()) < 1e-5
-    # a render of something else drops the prefetched march -- and its own march + sort, which may run at the same time as
-    # the prefetched ones on the side stream (one rocPRIM workspace per stream), are not disturbed by them
-    other = torch.tensor(poses[3], device=dev)
-    ref_other = r.render(other, None, training=True, pix_subset=pix)['rgb_map'].detach().clone()
+    pa, pb = torch.tensor(poses[2], device=dev), torch.tensor(poses[3], device=dev)
+    with torch.no_grad():
+        ref_a = r.render(pa, None, training=True, pix_subset=pix)['rgb_map'].clone()
+        ref_b = r.render(pb, None, training=True, pix_subset=pix)['rgb_map'].clone()
     torch.cuda.synchronize()
-    assert r.prefetch_train(pose, pix)
-    out = r.render(other, None, training=True, pix_subset=pix)
-    assert r._prefetched is None and not torch.equal(out['rgb_map'].detach(), rgb0)
-    assert torch.equal(out['rgb_map'].detach(), ref_other)
-    m.arena.grad.zero_()
-    torch.mean((out['rgb_map'] - tgt) ** 2).backward()
-    g_conc = m.arena.grad.clone()
-    m.arena.grad.zero_()
+    side = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.enable_grad():
+        with torch.cuda.stream(side):
+            out_b = r.render(pb, None, training=True, pix_subset=pix)['rgb_map']
+        out_a = r.render(pa, None, training=True, pix_subset=pix)['rgb_map']
+    torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
-    o2 = r.render(other, None, training=True, pix_subset=pix)
-    torch.mean((o2['rgb_map'] - tgt) ** 2).backward()
-    assert rel_l2(g_conc.cpu().numpy(), m.arena.grad.cpu().numpy()) < 1e-5
-    # in front of an occupancy update nothing is prefetched
-    r.update_occ = True
-    r.local_step = r.cfg.update_iter * 3
-    assert not r.prefetch_train(pose, pix)
-    r.update_occ = False
+    assert torch.equal(out_a.detach(), ref_a) and torch.equal(out_b.detach(), ref_b)
+

@@ -104,7 +104,7 @@ def test_checkpoint_layout_roundtrip_and_refusal(tmp_path):
     r.density_grid[0, :100] = 3.0
     r.local_step, r.mean_count = 17, 123
     sc = LossScaler()
-    sc.scale_value, sc._good_steps = 1024.0, 5
+    sc.load_state_dict(dict(sc.state_dict(), scale=1024.0, _growth_tracker=5, steps=17))
     p = tmp_path / 'iter_0017.pth'
     C.save_checkpoint(p, r, scaler=sc, iter_ctr=17, log_dir=tmp_path, train_cfg={'num_rays_per_batch': 4096})
     sd = C.load_checkpoint(p)
@@ -119,7 +119,7 @@ def test_checkpoint_layout_roundtrip_and_refusal(tmp_path):
     assert C.restore(sd, r2, scaler=sc2) == 17
     assert torch.equal(m2.arena.detach(), m.arena.detach())
     assert torch.equal(r2.density_grid, r.density_grid) and r2.local_step == 17 and r2.mean_count == 123
-    assert sc2.scale_value == 1024.0 and sc2._good_steps == 5
+    assert sc2.get_scale() == 1024.0 and sc2.state_dict()['_growth_tracker'] == 5 and sc2.state_dict()['steps'] == 17
     # a checkpoint with pickled class instances, as the reference writes them: refused, not executed
     bad = tmp_path / 'reference_style.pth'
     torch.save({'renderer': {'intr': intr}, 'render_cfg': RendererConfig.llff()}, bad)
