@@ -304,6 +304,7 @@ def run_recon(args, dev, rank, world):
     loss_scale = 65536.0 if args.compute_dtype == 'f16' else 1.0
     scaler = None if args.no_loss_scaler else LossScaler(init_scale=65536.0, enabled=(args.compute_dtype == 'f16'))
     scale_t = scaler.scale_tensor(dev) if scaler is not None else None
+    loss_scale_t = torch.tensor(loss_scale, dtype=torch.float32, device=dev)
     opt = FusedAdam(model, lr=1e-2, betas=(0.9, 0.999), eps=1e-15, ema_decay=0.95)
     npix = intr.w * intr.h
     n_rays = min(args.rays_per_gpu, npix)
@@ -318,19 +319,20 @@ def run_recon(args, dev, rank, world):
     overflow = torch.zeros(1, dtype=torch.int64, device=dev)
     sp_lambda, sp_coeff, sp_n = args.sparsity_lambda, 0.05, 50000          # cfgs/training/default.yaml:17-19
 
+    from nerfstyle_amd.recon_loss import recon_loss
+
     def loss_fn(out, pix):
-        mse = torch.mean((out['rgb_map'] - target_rgb[pix]) ** 2)
-        # cross entropy (trainers/base.py:281, nn.CrossEntropyLoss) as logsumexp - picked logit: same value and
-        # gradient, without torch's one-block nll_loss reduction kernels (0.9 ms per 762 048-ray step)
-        logits = out['classes']
-        ce = (torch.logsumexp(logits, dim=1) - logits.gather(1, target_cls[pix][:, None])[:, 0]).mean() * 1e-3
-        total = mse + ce
+        # trainers/base.py:251-304: MSE + 0.001 * cross-entropy on the class logits -- one fused kernel for value and gradient
+        # (nsr_recon_loss: target gather, loss scale and 1 / world folded in)
+        total = recon_loss(out['rgb_map'], out['classes'], target_rgb, target_cls, pix, ce_lambda=1e-3, factor=1.0 / world,
+                           scale=scale_t if scale_t is not None else loss_scale_t)
         if sp_lambda > 0:
             # trainers/base.py:409-413: sigma of 50 000 uniform points of the bbox, WITH autograd; :285-291: the loss
             pts = torch.rand(sp_n, 3, device=dev, generator=gen) * 4.0 - 2.0
             sig = model(pts)
-            total = total + torch.mean(torch.abs(1 - torch.exp(-sp_coeff * sig))) * sp_lambda
-        return total * (scale_t / world) if scale_t is not None else total * (loss_scale / world)
+            sp = torch.mean(torch.abs(1 - torch.exp(-sp_coeff * sig))) * sp_lambda
+            total = total + sp * ((scale_t if scale_t is not None else loss_scale_t) / world)
+        return total
 
     graphed = None
     if args.graph:

@@ -116,6 +116,37 @@ int nsr_composite_rays_train_backward(const float *grad_weights_sum, const float
                                       uint32_t C, float T_thresh, float *grad_sigmas, float *grad_rgbs,
                                       nsr_stream_t stream);
 
+/* Training composite + the epilogue of Renderer.render_train (renderer.py:225-233) in one launch (no reference
+ * counterpart: the reference runs composite_rays_train, then torch ops for `image + (1 - weights_sum)`, the class slice
+ * and `clamp(depth - nears, 0) / (fars - nears)`).  Same arithmetic as nsr_composite_rays_train_forward; additionally
+ * writes rgb_map [N,3] = image[:, :3] + (1 - weights_sum), classes [N, C-3] = image[:, 3:] (NULL allowed when C == 3) and
+ * depth_norm [N].  weights_sum, depth (raw) and image [N,C] are still written (the backward reads weights_sum / image). */
+int nsr_render_train_forward(const float *sigmas, const float *rgbs, const float *deltas, const int32_t *rays,
+                             const float *nears, const float *fars, uint32_t M, uint32_t N, uint32_t C, float T_thresh,
+                             float *weights_sum, float *depth, float *image, float *rgb_map, float *depth_norm,
+                             float *classes, nsr_stream_t stream);
+/* Backward of nsr_render_train_forward with respect to sigmas / rgbs, from the gradients of rgb_map [N,3], classes
+ * [N, C-3] and weights_sum [N] (each may be NULL = zero; depth_norm carries no gradient, as in the reference whose
+ * composite backward ignores grad_depth, raymarching.py:333).  Every sample of every ray gets its gradient written. */
+int nsr_render_train_backward(const float *grad_rgb_map, const float *grad_classes, const float *grad_weights_sum,
+                              const float *sigmas, const float *rgbs, const float *deltas, const int32_t *rays,
+                              const float *weights_sum, const float *image, uint32_t M, uint32_t N, uint32_t C,
+                              float T_thresh, float *grad_sigmas, float *grad_rgbs, nsr_stream_t stream);
+
+/* Reconstruction loss of Trainer.calc_loss (trainers/base.py:251-304), value AND gradient in one pass:
+ *   loss = mean((rgb_map - target_rgb[pix])^2) + ce_lambda * mean(logsumexp(classes) - classes[target_cls[pix]])
+ * (nn.MSELoss + 0.001 * nn.CrossEntropyLoss on the class logits; the reference builds it from ~25 torch kernels and as
+ * many again in autograd).  pix [N] int64 = rows of the targets (NULL: row n); target_rgb [P,3] f32; target_cls [P] int64.
+ * classes == NULL, nc == 0 or ce_lambda == 0: MSE only (grad_classes untouched).
+ * Everything is multiplied by factor * (scale ? scale[0] : 1): `scale` is the device-side loss scale (nsr_scaler_update),
+ * `factor` e.g. 1 / world size.  loss_out [3] = {scaled total, unscaled mse, unscaled ce_lambda * ce}.  The value is summed in
+ * a fixed order (block tree + one-block final pass): run-to-run identical.
+ * workspace: nsr_recon_loss_workspace_bytes(N) bytes. */
+uint64_t nsr_recon_loss_workspace_bytes(uint32_t N);
+int nsr_recon_loss(const float *rgb_map, const float *classes, uint32_t N, uint32_t nc, const float *target_rgb,
+                   const int64_t *target_cls, const int64_t *pix, float ce_lambda, float factor, const float *scale,
+                   float *grad_rgb_map, float *grad_classes, float *loss_out, void *workspace, nsr_stream_t stream);
+
 /* replaces march_rays (raymarching.h:17, raymarching.cu:1004-1130), inference. */
 int nsr_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t *rays_alive, const float *rays_t,
                    const float *rays_o, const float *rays_d, const float *z_hats, float bound,

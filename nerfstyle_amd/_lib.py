@@ -49,6 +49,10 @@ SIGNATURES = {
                                    vp, vp, vp, vp]),
     'nsr_composite_rays_train_forward': (i32, [vp, vp, vp, vp, u32, u32, u32, f32, i32, vp, vp, vp, vp]),
     'nsr_composite_rays_train_backward': (i32, [vp, vp, vp, vp, vp, vp, i32, vp, vp, u32, u32, u32, f32, vp, vp, vp]),
+    'nsr_render_train_forward': (i32, [vp, vp, vp, vp, vp, vp, u32, u32, u32, f32, vp, vp, vp, vp, vp, vp, vp]),
+    'nsr_render_train_backward': (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, u32, u32, u32, f32, vp, vp, vp]),
+    'nsr_recon_loss_workspace_bytes': (u64, [u32]),
+    'nsr_recon_loss': (i32, [vp, vp, u32, u32, vp, vp, vp, f32, f32, vp, vp, vp, vp, vp, vp]),
     'nsr_march_rays': (i32, [u32, u32, vp, vp, vp, vp, vp, f32, f32, u32, i32, u32, u32, vp, vp, vp, vp, vp, vp, vp,
                              vp]),
     'nsr_composite_rays': (i32, [u32, u32, f32, vp, vp, vp, vp, vp, u32, i32, vp, vp, vp, vp]),

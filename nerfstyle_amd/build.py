@@ -13,7 +13,7 @@ CSRC = os.path.join(HERE, 'csrc')
 OBJ = os.path.join(HERE, 'csrc', '_obj')
 LIB = os.path.join(HERE, 'libnsr_hip.so')
 ARCH = 'gfx950'
-SOURCES = ['raymarch.hip', 'occupancy.hip', 'sample_order.hip', 'gridenc.hip', 'field.hip', 'field_bwd.hip', 'field_bwd_gout.hip', 'table_scatter.hip', 'mlp.hip',
+SOURCES = ['raymarch.hip', 'composite.hip', 'occupancy.hip', 'sample_order.hip', 'gridenc.hip', 'field.hip', 'field_bwd.hip', 'field_bwd_gout.hip', 'table_scatter.hip', 'mlp.hip',
            'optim.hip']
 # MFMA destinations in VGPRs (no AGPR round trip for results that VALU code consumes next): the forward, and the GOUT backward,
 # whose 240 weight-gradient accumulators are pinned to AGPRs by inline assembly instead (field_bwd.hip)

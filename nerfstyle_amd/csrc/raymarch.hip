@@ -462,166 +462,9 @@ k_march_wpr(const float *__restrict__ rays_o, const float *__restrict__ rays_d, 
 }
 
 // ---------------------------------------------------------------------------------------------
-// compositing (training)
+// compositing: the training composite lives in composite.hip (wave per ray, lane per sample)
 // ---------------------------------------------------------------------------------------------
 #define RM_MAXC 16
-#ifndef RM_CU
-#define RM_CU 8u      // composite steps whose loads are issued together
-#endif
-
-// Training composite, coalesced form.  The reference runs one thread per ray over [M, C] arrays
-// (raymarching.cu:806-879, 904-986): every load of a wave touches 64 different lines (measured
-// 221 / 282 B of HBM traffic per sample against ~56 algorithmic).  Here a ray is owned by a group
-// of LPR lanes (LPR = 4, 8 or 16 >= C), lane c of the group owns channel c: the group's rgbs /
-// grad_rgbs access of a sample is one contiguous C*4-byte piece, sigma / deltas are a broadcast
-// address, consecutive steps walk consecutive memory.  The scalar recurrences (T, ws, depth) are
-// evaluated redundantly by every lane of the group, in the reference's operation order.
-
-// raymarching.cu:806-879
-template <int LPR>
-__global__ void __launch_bounds__(RM_BLOCK)
-k_composite_train_fwd(const float *__restrict__ sigmas, const float *__restrict__ rgbs, const float *__restrict__ deltas,
-                      const int32_t *__restrict__ rays, uint32_t M, uint32_t N, uint32_t C, float T_thresh, int is_ndc,
-                      float *__restrict__ weights_sum, float *__restrict__ depth, float *__restrict__ image) {
-    const uint32_t tid = blockIdx.x * RM_BLOCK + threadIdx.x;
-    const uint32_t n = tid / LPR, ch = tid % LPR;
-    if (n >= N) return;
-    const uint32_t index = (uint32_t)rays[n * 3], offset = (uint32_t)rays[n * 3 + 1], num_steps = (uint32_t)rays[n * 3 + 2];
-    const bool has_ch = ch < C;
-    float acc = 0.0f;
-    float T = 1.0f, ws = 0.0f, t = 0.0f, d = 0.0f;
-    if (!(num_steps == 0 || offset + num_steps >= M)) {
-        const float *s = sigmas + offset;
-        const float *rgb = rgbs + (size_t)offset * C + (has_ch ? ch : 0);
-        const float *dl = deltas + (size_t)offset * 4;
-        // RM_CU steps per trip: their loads are issued together (indices clamped into the ray, so the
-        // speculation past an early stop stays in bounds) -- the recurrence on T is serial, the memory
-        // latency in front of it need not be paid once per step
-        // ... and the NEXT trip's loads are in flight while this trip is evaluated (a wave spent 86 % of its
-        // cycles waiting with one trip at a time)
-        bool stop = false;
-        float sv[RM_CU], cv[RM_CU];
-        float2 dv[RM_CU];
-        auto load_trip = [&](uint32_t base, float (&a)[RM_CU], float (&b)[RM_CU], float2 (&e)[RM_CU]) {
-#pragma unroll
-            for (uint32_t u = 0; u < RM_CU; u++) {
-                const uint32_t st = min(base + u, num_steps - 1);
-                e[u] = is_ndc ? *reinterpret_cast<const float2 *>(dl + st * 4 + 2) : *reinterpret_cast<const float2 *>(dl + st * 4);
-                a[u] = s[st];
-                b[u] = rgb[(size_t)st * C];
-            }
-        };
-        load_trip(0, sv, cv, dv);
-        for (uint32_t base = 0; base < num_steps && !stop; base += RM_CU) {
-            float nsv[RM_CU], ncv[RM_CU];
-            float2 ndv[RM_CU];
-            load_trip(base + RM_CU, nsv, ncv, ndv);
-#pragma unroll
-            for (uint32_t u = 0; u < RM_CU; u++) {
-                if (base + u >= num_steps) { stop = true; break; }
-                const float alpha = 1.0f - __expf(-sv[u] * dv[u].x);
-                const float weight = alpha * T;
-                if (has_ch) acc += weight * cv[u];
-                t += dv[u].y;
-                d += weight * t;
-                ws += weight;
-                T *= 1.0f - alpha;
-                if (T < T_thresh) { stop = true; break; }   // :862
-            }
-#pragma unroll
-            for (uint32_t u = 0; u < RM_CU; u++) { sv[u] = nsv[u]; cv[u] = ncv[u]; dv[u] = ndv[u]; }
-        }
-    }
-    if (ch == 0) {
-        weights_sum[index] = ws;
-        depth[index] = d;
-    }
-    if (has_ch) image[(size_t)index * C + ch] = acc;
-}
-
-// raymarching.cu:904-986.  rgbs_buf lives in registers (one channel per lane).
-template <int LPR>
-__global__ void __launch_bounds__(RM_BLOCK)
-k_composite_train_bwd(const float *__restrict__ grad_weights_sum, const float *__restrict__ grad_image,
-                      const float *__restrict__ sigmas, const float *__restrict__ rgbs, const float *__restrict__ deltas,
-                      const int32_t *__restrict__ rays, int is_ndc, const float *__restrict__ weights_sum,
-                      const float *__restrict__ image, uint32_t M, uint32_t N, uint32_t C, float T_thresh,
-                      float *__restrict__ grad_sigmas, float *__restrict__ grad_rgbs, int zero_fill) {
-    const uint32_t tid = blockIdx.x * RM_BLOCK + threadIdx.x;
-    // whole lane groups must stay converged for the cross-lane sums below: no early return
-    const uint32_t n = min(tid / LPR, N - 1), ch = tid % LPR;
-    const bool ray_ok = tid / LPR < N;
-    const uint32_t index = (uint32_t)rays[n * 3], offset = (uint32_t)rays[n * 3 + 1];
-    const uint32_t num_steps = ray_ok ? (uint32_t)rays[n * 3 + 2] : 0u;
-    const bool has_ch = ch < C;
-    const bool dropped = offset + num_steps >= M;
-    float *gs = grad_sigmas + offset;
-    float *grgb = grad_rgbs + (size_t)offset * C + (has_ch ? ch : 0);
-    if (num_steps != 0 && dropped) {
-        // dropped ray (:929): the reference leaves its pre-zeroed gradients untouched; write the
-        // zeros here (inside the buffer only) so that callers need no memset of [M, 1 + C]
-        if (zero_fill) {
-            for (uint32_t step = 0; step < num_steps && offset + step < M; step++) {
-                if (ch == 0) gs[step] = 0.0f;
-                if (has_ch) grgb[(size_t)step * C] = 0.0f;
-            }
-        }
-    }
-    const uint32_t steps = dropped ? 0u : num_steps;
-    const float gim = (has_ch && steps) ? grad_image[(size_t)index * C + ch] : 0.0f;
-    const float im = (has_ch && steps) ? image[(size_t)index * C + ch] : 0.0f;
-    const float gws = steps ? grad_weights_sum[index] : 0.0f;
-    const float ws_final = steps ? weights_sum[index] : 0.0f;
-    const float *s = sigmas + offset;
-    const float *rgb = rgbs + (size_t)offset * C + (has_ch ? ch : 0);
-    const float *dl = deltas + (size_t)offset * 4;
-    float buf = 0.0f, T = 1.0f;
-    // lanes of a group run the same trip count (same ray), different groups of a wave do not: the
-    // cross-lane sum uses DPP-free shuffles restricted to the group, executed by every live group
-    uint32_t step = 0;
-    bool stop = false;
-    float sv[RM_CU], cv[RM_CU], dlv[RM_CU];
-    auto load_trip = [&](uint32_t base, float (&a)[RM_CU], float (&b)[RM_CU], float (&e)[RM_CU]) {
-#pragma unroll
-        for (uint32_t u = 0; u < RM_CU; u++) {
-            const uint32_t st = min(base + u, steps ? steps - 1 : 0u);
-            e[u] = steps ? (is_ndc ? dl[st * 4 + 2] : dl[st * 4 + 0]) : 0.0f;
-            a[u] = steps ? s[st] : 0.0f;
-            b[u] = (has_ch && steps) ? rgb[(size_t)st * C] : 0.0f;
-        }
-    };
-    load_trip(0, sv, cv, dlv);
-    for (uint32_t base = 0; base < steps && !stop; base += RM_CU) {
-        float nsv[RM_CU], ncv[RM_CU], ndlv[RM_CU];
-        load_trip(base + RM_CU, nsv, ncv, ndlv);          // the next trip's loads fly during this trip
-#pragma unroll
-        for (uint32_t u = 0; u < RM_CU; u++) {
-            if (base + u >= steps) { stop = true; break; }
-            const float delta = dlv[u];
-            const float alpha = 1.0f - __expf(-sv[u] * delta);
-            const float weight = alpha * T;
-            const float c = cv[u];
-            buf += weight * c;
-            T *= 1.0f - alpha;
-            if (T < T_thresh) { stop = true; break; }   // :961
-            if (has_ch) grgb[(size_t)step * C] = gim * weight;
-            float gsum = has_ch ? gim * (T * c - (im - buf)) : 0.0f;
-#pragma unroll
-            for (int off = LPR / 2; off >= 1; off >>= 1) gsum += __shfl_xor(gsum, off, LPR);
-            if (ch == 0) gs[step] = delta * (gsum + gws * (1 - ws_final));
-            step++;
-        }
-#pragma unroll
-        for (uint32_t u = 0; u < RM_CU; u++) { sv[u] = nsv[u]; cv[u] = ncv[u]; dlv[u] = ndlv[u]; }
-    }
-    // samples at and after the early stop keep the zero gradient the reference pre-fills
-    if (zero_fill) {
-        for (; step < steps; step++) {
-            if (ch == 0) gs[step] = 0.0f;
-            if (has_ch) grgb[(size_t)step * C] = 0.0f;
-        }
-    }
-}
 
 // Single-pass inference composite: the arithmetic of kernel_composite_rays (raymarching.cu:1133-1231)
 // -- T = 1 - weight_sum, stop test on T BEFORE the sample (:1206), absolute t starting at near --
@@ -924,42 +767,6 @@ int nsr_march_rays_train(const float *rays_o, const float *rays_d, const float *
     hipLaunchKernelGGL(k_scan_block_sums, dim3(1), dim3(1024), 0, s, block_sums, nblocks, counter, N);
     hipLaunchKernelGGL(k_march_emit, dim3(nblocks), dim3(RM_BLOCK), 0, s, rays_o, rays_d, z_hats, grid, bound, dt_gamma,
                        max_steps, is_ndc, N, C, H, M, nears, fars, noises, counts, block_sums, 0u, xyzs, dirs, deltas, rays);
-    return nsr_launch_status();
-}
-
-int nsr_composite_rays_train_forward(const float *sigmas, const float *rgbs, const float *deltas, const int32_t *rays,
-                                     uint32_t M, uint32_t N, uint32_t C, float T_thresh, int is_ndc, float *weights_sum,
-                                     float *depth, float *image, nsr_stream_t stream) {
-    if (N == 0) return NSR_OK;
-    NSR_CHECK_PTR(sigmas); NSR_CHECK_PTR(rgbs); NSR_CHECK_PTR(deltas); NSR_CHECK_PTR(rays);
-    NSR_CHECK_PTR(weights_sum); NSR_CHECK_PTR(depth); NSR_CHECK_PTR(image);
-    if (C == 0 || C > RM_MAXC) return NSR_ERR_UNSUPPORTED;
-    hipStream_t hs = (hipStream_t)stream;
-    if (((uintptr_t)deltas & 7u) != 0) return NSR_ERR_INVALID_ARG;
-#define NSR_CF(LPR)                                                                                              \
-    hipLaunchKernelGGL((k_composite_train_fwd<LPR>), dim3(nsr_div_up((uint64_t)N * LPR, RM_BLOCK)), dim3(RM_BLOCK), 0, hs, \
-                       sigmas, rgbs, deltas, rays, M, N, C, T_thresh, is_ndc, weights_sum, depth, image)
-    if (C <= 4) NSR_CF(4); else if (C <= 8) NSR_CF(8); else NSR_CF(16);
-#undef NSR_CF
-    return nsr_launch_status();
-}
-
-int nsr_composite_rays_train_backward(const float *grad_weights_sum, const float *grad_image, const float *sigmas,
-                                      const float *rgbs, const float *deltas, const int32_t *rays, int is_ndc,
-                                      const float *weights_sum, const float *image, uint32_t M, uint32_t N, uint32_t C,
-                                      float T_thresh, float *grad_sigmas, float *grad_rgbs, nsr_stream_t stream) {
-    if (N == 0) return NSR_OK;
-    NSR_CHECK_PTR(grad_weights_sum); NSR_CHECK_PTR(grad_image); NSR_CHECK_PTR(sigmas); NSR_CHECK_PTR(rgbs);
-    NSR_CHECK_PTR(deltas); NSR_CHECK_PTR(rays); NSR_CHECK_PTR(weights_sum); NSR_CHECK_PTR(image);
-    NSR_CHECK_PTR(grad_sigmas); NSR_CHECK_PTR(grad_rgbs);
-    if (C == 0 || C > RM_MAXC) return NSR_ERR_UNSUPPORTED;
-    hipStream_t hs = (hipStream_t)stream;
-#define NSR_CB(LPR)                                                                                              \
-    hipLaunchKernelGGL((k_composite_train_bwd<LPR>), dim3(nsr_div_up((uint64_t)N * LPR, RM_BLOCK)), dim3(RM_BLOCK), 0, hs, \
-                       grad_weights_sum, grad_image, sigmas, rgbs, deltas, rays, is_ndc, weights_sum, image, M, N, C, T_thresh, \
-                       grad_sigmas, grad_rgbs, 1)
-    if (C <= 4) NSR_CB(4); else if (C <= 8) NSR_CB(8); else NSR_CB(16);
-#undef NSR_CB
     return nsr_launch_status();
 }
 

@@ -228,14 +228,12 @@ class Renderer(torch.nn.Module):
                 'rays_info': rays_info}
 
     def shade_train(self, mt: dict, perm=None):
-        """fused field on the marched samples + train composite + the epilogue of renderer.py:225-233"""
+        """fused field on the marched samples + train composite with the epilogue of renderer.py:225-233 folded in
+        (nsr_render_train_forward / _backward): two autograd nodes, no torch glue between them"""
         sigmas, rgbs = self.model.field(mt['xyzs'], sigma_only=False, m_dev=mt['counter'], density_scale=self.cfg.density_scale,
                                         perm=perm)
-        weights_sum, depth, image = _composite_train_nosync(sigmas, rgbs, mt['deltas'], mt['rays_info'], self.cfg.t_thresh)
-        classes = image[:, 3:]
-        image = image[:, :3]
-        image = image + (1 - weights_sum).unsqueeze(-1)
-        depth = torch.clamp(depth - mt['nears'], min=0) / (mt['fars'] - mt['nears'])
+        image, depth, classes, _ = _render_train(sigmas, rgbs, mt['deltas'], mt['rays_info'], mt['nears'], mt['fars'],
+                                                 self.cfg.t_thresh)
         return image, depth, classes
 
     def _use_spatial_order(self, n_rays: int, dense: bool) -> bool:
@@ -340,44 +338,53 @@ class Renderer(torch.nn.Module):
         return output
 
 
-class _composite_train_nosync_fn(torch.autograd.Function):
-    """composite_rays_train over capacity-sized buffers: gradients are produced with torch.empty
-    (the backward kernel writes every sample that belongs to a ray, zeros included)."""
+class _render_train_fn(torch.autograd.Function):
+    """composite_rays_train (raymarching.cu:806-997) + `image[:, :3] + (1 - weights_sum)`, the class slice and the depth
+    normalisation (renderer.py:229-233) as ONE kernel each way, over capacity-sized sample buffers.  Outputs
+    (rgb_map [N,3], depth [N], classes [N,nc], weights_sum [N]); gradients are produced with torch.empty (the backward kernel
+    writes every sample that belongs to a ray, zeros included)."""
 
     @staticmethod
-    def forward(ctx, sigmas, rgbs, deltas, rays, T_thresh):
+    def forward(ctx, sigmas, rgbs, deltas, rays, nears, fars, T_thresh):
         from . import _lib as L
+        from . import profiling
         M, N, C = sigmas.shape[0], rays.shape[0], rgbs.shape[1]
         dev = sigmas.device
         weights_sum = torch.empty(N, dtype=torch.float32, device=dev)
-        depth = torch.empty(N, dtype=torch.float32, device=dev)
+        depth_raw = torch.empty(N, dtype=torch.float32, device=dev)
         image = torch.empty(N, C, dtype=torch.float32, device=dev)
-        from . import profiling
+        rgb_map = torch.empty(N, 3, dtype=torch.float32, device=dev)
+        depth = torch.empty(N, dtype=torch.float32, device=dev)
+        classes = torch.empty(N, C - 3, dtype=torch.float32, device=dev)
         with profiling.timed('composite_fwd'):
-            L.check(L.lib().nsr_composite_rays_train_forward(
-                L.p(sigmas), L.p(rgbs), L.p(deltas), L.p(rays), M, N, C, float(T_thresh), 0, L.p(weights_sum), L.p(depth),
-                L.p(image), L.stream()), 'composite_rays_train_forward')
+            L.check(L.lib().nsr_render_train_forward(
+                L.p(sigmas), L.p(rgbs), L.p(deltas), L.p(rays), L.p(nears), L.p(fars), M, N, C, float(T_thresh), L.p(weights_sum),
+                L.p(depth_raw), L.p(image), L.p(rgb_map), L.p(depth), L.p(classes) if C > 3 else None, L.stream()),
+                'render_train_forward')
         ctx.save_for_backward(sigmas, rgbs, deltas, rays, weights_sum, image)
         ctx.T_thresh = T_thresh
         ctx.mark_non_differentiable(depth)
-        return weights_sum, depth, image
+        return rgb_map, depth, classes, weights_sum
 
     @staticmethod
-    def backward(ctx, grad_weights_sum, grad_depth, grad_image):
+    def backward(ctx, g_rgb, g_depth, g_classes, g_ws):
         from . import _lib as L
+        from . import profiling
         sigmas, rgbs, deltas, rays, weights_sum, image = ctx.saved_tensors
         M, N, C = sigmas.shape[0], rays.shape[0], rgbs.shape[1]
-        grad_weights_sum = grad_weights_sum.to(torch.float32).contiguous()
-        grad_image = grad_image.to(torch.float32).contiguous()
+
+        def prep(g):
+            return None if g is None else g.to(torch.float32).contiguous()
+        g_rgb, g_classes, g_ws = prep(g_rgb), prep(g_classes), prep(g_ws)
+        if C == 3:
+            g_classes = None
         grad_sigmas = torch.empty_like(sigmas)
         grad_rgbs = torch.empty_like(rgbs)
-        from . import profiling
         with profiling.timed('composite_bwd'):
-            L.check(L.lib().nsr_composite_rays_train_backward(
-                L.p(grad_weights_sum), L.p(grad_image), L.p(sigmas), L.p(rgbs), L.p(deltas), L.p(rays), 0, L.p(weights_sum),
-                L.p(image), M, N, C, float(ctx.T_thresh), L.p(grad_sigmas), L.p(grad_rgbs), L.stream()),
-                'composite_rays_train_backward')
-        return grad_sigmas, grad_rgbs, None, None, None
+            L.check(L.lib().nsr_render_train_backward(
+                L.p(g_rgb), L.p(g_classes), L.p(g_ws), L.p(sigmas), L.p(rgbs), L.p(deltas), L.p(rays), L.p(weights_sum), L.p(image),
+                M, N, C, float(ctx.T_thresh), L.p(grad_sigmas), L.p(grad_rgbs), L.stream()), 'render_train_backward')
+        return grad_sigmas, grad_rgbs, None, None, None, None, None
 
 
-_composite_train_nosync = _composite_train_nosync_fn.apply
+_render_train = _render_train_fn.apply

@@ -22,7 +22,7 @@ def test_full_frame_762048_rays(O, dev):
     from nerfstyle_amd.common import BBox
     from nerfstyle_amd.config import NetworkConfig, RendererConfig
     from nerfstyle_amd.rays import generate_rays
-    from nerfstyle_amd.renderer import Renderer, _composite_train_nosync
+    from nerfstyle_amd.renderer import Renderer, _render_train
     from nerfstyle_amd.scene import load_room_cameras, synthetic_density_grid
     from nerfstyle_amd.style_nerf import StyleTCNerf
     from oracle import torch_port as TP
@@ -94,7 +94,8 @@ def test_full_frame_762048_rays(O, dev):
     assert rel_l2(rgbs[pick].cpu().numpy(), out_o) < 3e-3
     # ---- composite: ws + prod(1 - alpha) = 1 where the ray did not stop early ------------------
     with torch.no_grad():
-        ws, depth, image = _composite_train_nosync(sigmas, rgbs, deltas, rays_info, cfg.t_thresh)
+        rgb_map, depth, classes, ws = _render_train(sigmas, rgbs, deltas, rays_info, nears, fars, cfg.t_thresh)
+        image = torch.cat((rgb_map - (1 - ws).unsqueeze(-1), classes), 1)
     tau = torch.zeros(M + 1, dtype=torch.float64, device=dev)
     tau[1:total + 1] = torch.cumsum((sigmas[:total].double() * deltas[:total, 0].double()), 0)
     T_final = torch.exp(-(tau[off + cnt] - tau[off]))
@@ -103,4 +104,5 @@ def test_full_frame_762048_rays(O, dev):
     assert float((ws[live].double() + T_final[live] - 1.0).abs().max()) < 2e-4
     empty = cnt == 0
     assert int(empty.sum()) > 0 and float(ws[empty].abs().max()) == 0.0 and float(image[empty].abs().max()) == 0.0
+    assert float((rgb_map[empty] - 1.0).abs().max()) == 0.0                # white background
     assert torch.isfinite(image).all() and torch.isfinite(depth).all()

@@ -119,6 +119,115 @@ def test_composite_train_forward_backward(O, dev, C):
     assert np.array_equal(gs == 0, gs_o == 0)
 
 
+def test_composite_train_kernel_vs_reference_integrate_points_golden(O, dev, golden):
+    """The HIP composite itself (nsr_composite_rays_train_forward, through the C ABI) against output of the REFERENCE:
+    nerf_lib.integrate_points run on seeded [N, K = 64] inputs by tests/golden/make_goldens.py (ip_* fixtures).  With no early
+    stop (T_thresh = 0) raymarching.cu's composite and integrate_points are the same quadrature.  64 samples per ray is exactly
+    one wave trip of the kernel; a second case puts 70 zero-density samples in front of every ray (134 samples = three trips):
+    the result must not change, which exercises the carries between trips."""
+    from nerfstyle_amd import raymarching as R
+    dists, rgbs, dens = golden['ip_dists'], golden['ip_rgbs'], golden['ip_dens']
+    N, K = dists.shape
+    deltas = np.zeros((N * K + 1, 4), np.float32)
+    deltas[:N * K, 0] = dists.reshape(-1)
+    deltas[:N * K, 1] = dists.reshape(-1)
+    rays = np.stack([np.arange(N), np.arange(N) * K, np.full(N, K)], 1).astype(np.int32)
+    sig = np.concatenate([dens.reshape(-1), [0]]).astype(np.float32)
+    rgb = np.concatenate([rgbs.reshape(-1, 3), np.zeros((1, 3))]).astype(np.float32)
+    ws, depth, image = R.composite_rays_train(T(sig, dev), T(rgb, dev), T(deltas, dev), T(rays, dev), 0.0, False)
+    assert np.allclose(image.cpu().numpy(), golden['ip_rgb_map'], atol=3e-6)
+    assert np.allclose(ws.cpu().numpy()[:, None], golden['ip_acc_map'], atol=3e-6)
+    # the same rays with 70 zero-density samples in front: 134 samples = three wave trips, carries across the trips
+    pad = 70
+    K2 = K + pad
+    d2 = np.zeros((N * K2 + 1, 4), np.float32)
+    s2 = np.zeros(N * K2 + 1, np.float32)
+    r2 = np.zeros((N * K2 + 1, 3), np.float32)
+    dd = np.concatenate([np.full((N, pad), 0.01, np.float32), dists], 1)
+    d2[:N * K2, 0] = dd.reshape(-1)
+    d2[:N * K2, 1] = dd.reshape(-1)
+    s2[:N * K2] = np.concatenate([np.zeros((N, pad), np.float32), dens.reshape(N, K)], 1).reshape(-1)
+    r2[:N * K2] = np.concatenate([np.ones((N, pad, 3), np.float32), rgbs.reshape(N, K, 3)], 1).reshape(-1, 3)
+    rays2 = np.stack([np.arange(N), np.arange(N) * K2, np.full(N, K2)], 1).astype(np.int32)
+    ws2, _, image2 = R.composite_rays_train(T(s2, dev), T(r2, dev), T(d2, dev), T(rays2, dev), 0.0, False)
+    assert np.allclose(image2.cpu().numpy(), golden['ip_rgb_map'], atol=3e-6)
+    assert np.allclose(ws2.cpu().numpy()[:, None], golden['ip_acc_map'], atol=3e-6)
+
+
+@pytest.mark.parametrize('C', [8, 4, 5])
+def test_render_train_epilogue_fused_equals_composite_plus_torch(O, dev, C):
+    """nsr_render_train_forward / _backward (composite + white background + class slice + depth normalisation,
+    renderer.py:225-233, in one launch each way) against composite_rays_train followed by those torch expressions, values and
+    the gradients w.r.t. sigmas / rgbs, for losses that use rgb_map, classes and weights_sum."""
+    from nerfstyle_amd import raymarching as R
+    from nerfstyle_amd.renderer import _render_train
+    sig, rgb, deltas, rays, near, far = _composite_inputs(O, 3000, C, seed=10 + C)
+    g = np.random.default_rng(3)
+    w_rgb, w_cls, w_ws = g.standard_normal((len(rays), 3)).astype(np.float32), g.standard_normal((len(rays), C - 3)).astype(np.float32), \
+        g.standard_normal(len(rays)).astype(np.float32)
+
+    def run(fused):
+        s_t, r_t = T(sig, dev).requires_grad_(), T(rgb, dev).requires_grad_()
+        if fused:
+            rgb_map, depth, classes, ws = _render_train(s_t, r_t, T(deltas, dev), T(rays, dev), T(near, dev), T(far, dev), 1e-4)
+        else:
+            ws, d, image = R.composite_rays_train(s_t, r_t, T(deltas, dev), T(rays, dev), 1e-4, False)
+            rgb_map = image[:, :3] + (1 - ws).unsqueeze(-1)
+            classes = image[:, 3:]
+            depth = torch.clamp(d - T(near, dev), min=0) / (T(far, dev) - T(near, dev))
+        loss = (rgb_map * T(w_rgb, dev)).sum() + (classes * T(w_cls, dev)).sum() + (ws * T(w_ws, dev)).sum()
+        loss.backward()
+        return [x.detach().cpu().numpy() for x in (rgb_map, depth, classes, ws, s_t.grad, r_t.grad)]
+    a, b = run(True), run(False)
+    # sample-buffer slots that belong to no ray (alignment padding) are never written by either path: compare the rays' samples
+    owned = np.zeros(len(sig), bool)
+    for n in range(len(rays)):
+        owned[rays[n, 1]:rays[n, 1] + rays[n, 2]] = True
+    a[4], b[4], a[5], b[5] = a[4][owned], b[4][owned], a[5][owned], b[5][owned]
+    for x, y, tol in zip(a, b, (1e-6, 1e-6, 1e-6, 1e-6, 1e-5, 1e-6)):
+        assert x.shape == y.shape and np.abs(x - y).max() <= tol * max(1.0, np.abs(y).max())
+    # a loss that ignores the classes (grad None) and one that only uses weights_sum
+    s_t, r_t = T(sig, dev).requires_grad_(), T(rgb, dev).requires_grad_()
+    rgb_map, depth, classes, ws = _render_train(s_t, r_t, T(deltas, dev), T(rays, dev), T(near, dev), T(far, dev), 1e-4)
+    rgb_map.sum().backward()
+    assert float(s_t.grad.abs().sum()) > 0 and float(r_t.grad[:, 3:].abs().sum()) == 0.0
+
+
+def test_recon_loss_value_and_gradient_equal_torch(dev):
+    """nsr_recon_loss (MSE + lambda * cross-entropy of trainers/base.py:251-304, value + gradient in one pass, targets
+    gathered through the pixel indices, times a device-side scale) against the torch expressions, to 1e-6 relative."""
+    from nerfstyle_amd.recon_loss import last_terms, recon_loss
+    g = torch.Generator(device=dev)
+    g.manual_seed(8)
+    for N, nc in ((5000, 5), (777, 13), (300000, 5)):
+        P = 2 * N + 3
+        rgb = torch.rand(N, 3, device=dev, generator=g).requires_grad_()
+        cls = (torch.randn(N, nc, device=dev, generator=g) * 3).requires_grad_()
+        t_rgb = torch.rand(P, 3, device=dev, generator=g)
+        t_cls = torch.randint(0, nc, (P,), device=dev, generator=g)
+        pix = torch.randperm(P, device=dev, generator=g)[:N]
+        scale = torch.tensor(1024.0, device=dev)
+        loss = recon_loss(rgb, cls, t_rgb, t_cls, pix, ce_lambda=1e-3, factor=0.5, scale=scale)
+        loss.backward()
+        rgb2, cls2 = rgb.detach().clone().requires_grad_(), cls.detach().clone().requires_grad_()
+        mse = torch.nn.functional.mse_loss(rgb2, t_rgb[pix])
+        ce = torch.nn.functional.cross_entropy(cls2, t_cls[pix]) * 1e-3
+        ref = (mse + ce) * 0.5 * scale
+        ref.backward()
+        assert abs(float(loss) - float(ref)) < 2e-6 * abs(float(ref))
+        terms = last_terms(loss).cpu().numpy()
+        assert abs(terms[0] - float(mse)) < 2e-6 * float(mse) and abs(terms[1] - float(ce)) < 2e-6 * float(ce)
+        assert float((rgb.grad - rgb2.grad).abs().max()) < 1e-6 * float(rgb2.grad.abs().max())
+        assert float((cls.grad - cls2.grad).abs().max()) < 1e-6 * float(cls2.grad.abs().max()) + 1e-12
+    # MSE only, no pixel indirection
+    rgb = torch.rand(1000, 3, device=dev, generator=g).requires_grad_()
+    tgt = torch.rand(1000, 3, device=dev, generator=g)
+    loss = recon_loss(rgb, None, tgt)
+    loss.backward()
+    assert abs(float(loss) - float(torch.mean((rgb.detach() - tgt) ** 2))) < 1e-7
+    assert float((rgb.grad - 2 * (rgb.detach() - tgt) / 3000).abs().max()) < 1e-9
+
+
 def test_inference_march_composite_loop(O, dev):
     """The render_test iteration (renderer.py:266-285) step by step against the oracle: alive sets,
     rays_t and accumulators after every iteration."""
