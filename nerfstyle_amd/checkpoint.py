@@ -7,8 +7,8 @@ The reference pickles its config dataclasses, a pathlib.Path and (inside `render
 by class reference.  Files written here hold the same keys but only tensors and plain containers
 (dataclasses become `{'__dataclass__': name, ...fields}` dicts, paths become strings), so they load with
 `torch.load(weights_only=True)` -- nothing from the file is executed.  A file written by the reference
-itself is refused by that loader; `load_checkpoint` says so and names the conversion to run inside the
-reference's own environment.  `renderer['model']` uses the reference's parameter
+itself names its config dataclasses, `common.Intrinsics` and `pathlib.PosixPath`: `load_checkpoint` reads it through the
+inert stand-ins of reference_schema.py on the weights-only allow-list (still nothing is executed); anything else is refused.  `renderer['model']` uses the reference's parameter
 names; the MLP `*.params` vectors are in the layout of nerfstyle_amd/network.py (tinycudann's internal
 layout is not part of the reference tree: "parity unpinned")."""
 import dataclasses
@@ -75,15 +75,20 @@ def save_checkpoint(path, renderer, optim=None, scaler=None, iter_ctr: int = 0, 
 
 
 def load_checkpoint(path, map_location='cpu') -> Dict[str, Any]:
-    """Safe load (weights_only): raises RuntimeError with the way out for reference-written files."""
+    """Safe load (weights_only).  A file of this build loads as it is; a file written by the reference names its config
+    dataclasses, common.Intrinsics and pathlib.PosixPath and is read through the inert stand-ins of reference_schema.py on
+    the weights-only allow-list.  Anything else raises RuntimeError; nothing from a checkpoint file is ever executed."""
     try:
         sd = torch.load(str(path), map_location=map_location, weights_only=True)
-    except pickle.UnpicklingError as e:
-        raise RuntimeError(
-            '{} holds pickled Python objects (the reference pickles its config dataclasses and Intrinsics): it is not '
-            'loaded here, nothing from a checkpoint file is executed.  Convert it once inside the reference '
-            'environment (INTEGRATION.md section 6: dataclasses.asdict on the config entries and on '
-            "renderer['intr'], str() on log_dir) and load the result.  Loader said: {}".format(path, e)) from None
+    except pickle.UnpicklingError:
+        from .reference_schema import load_reference_checkpoint
+        try:
+            sd = load_reference_checkpoint(path, map_location)
+        except (pickle.UnpicklingError, RuntimeError) as e:
+            raise RuntimeError(
+                "{} holds pickled Python objects outside the reference's checkpoint schema (config dataclasses, "
+                "common.Intrinsics, pathlib.PosixPath: those are read through inert stand-ins): it is not loaded, nothing from a "
+                "checkpoint file is executed.  Loader said: {}".format(path, e)) from None
     missing = [k for k in SAVE_KEYS + SD_SAVE_KEYS if k not in sd]
     if missing:
         raise RuntimeError('{} is not a trainer checkpoint: missing keys {}'.format(path, missing))
@@ -97,7 +102,15 @@ def restore(sd: Dict[str, Any], renderer, optim=None, scaler=None) -> int:
     rs['intr'] = intrinsics_from_plain(rs['intr'])
     renderer.load_state_dict(rs)
     if optim is not None and sd.get('optim') is not None:
-        optim.load_state_dict(sd['optim'])
+        if 'param_groups' in sd['optim'] and 'state' in sd['optim']:
+            # a reference-written file: torch.optim.Adam's and torch_ema's own state dicts
+            optim.load_reference_state(sd['optim'], sd.get('ema'))
+        else:
+            optim.load_state_dict(sd['optim'])
     if scaler is not None and sd.get('scaler') is not None and hasattr(scaler, 'load_state_dict'):
-        scaler.load_state_dict(sd['scaler'])
+        sc = dict(sd['scaler'])
+        if 'steps' not in sc and optim is not None:
+            # torch's GradScaler does not count optimiser steps; the device-side scaler does (bias corrections, LambdaLR)
+            sc['steps'] = int(optim.step_count)
+        scaler.load_state_dict(sc)
     return int(sd['iter_ctr'])

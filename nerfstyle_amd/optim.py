@@ -137,7 +137,49 @@ class FusedAdam:
         return {'step': self.steps_taken, 'exp_avg': self.exp_avg, 'exp_avg_sq': self.exp_avg_sq, 'ema': self.ema,
                 'ema_updates': self.ema_updates, 'lr': self.param_groups[0]['lr']}
 
+    def load_reference_state(self, optim_sd, ema_sd=None):
+        """State of the REFERENCE's optimiser objects: torch.optim.Adam.state_dict() ({'state': {i: {'step', 'exp_avg',
+        'exp_avg_sq'}}, 'param_groups': ...}, parameters in named_parameters() order filtered by the trainer's keywords,
+        trainers/base.py:185-221) and torch_ema's state_dict ({'decay', 'num_updates', 'shadow_params': [...]}, over ALL
+        model parameters, base.py:229) -> the flat arenas kept here."""
+        m = self.model
+        trained = set(off for off, _ in self.nets)
+        names = []
+        if self.table_mask & 0x3:
+            names.append('x_density_embedder.embeddings')
+        if self.table_mask & 0xC:
+            names.append('x_color_embedder.embeddings')
+        names += [name + '.params' for (name, off, n) in MLP_LAYOUT if off in trained]
+        state = optim_sd['state']
+        keys = sorted(state.keys(), key=int)
+        if len(keys) != len(names):
+            raise RuntimeError('optimiser state holds {} parameters, this optimiser trains {} ({})'.format(len(keys), len(names), names))
+
+        def views(flat):
+            t = flat[:m.table_elems].view(m.rows, 2, 2)
+            out = {'x_density_embedder.embeddings': t[:, 0, :], 'x_color_embedder.embeddings': t[:, 1, :]}
+            for (name, off, n) in MLP_LAYOUT:
+                out[name + '.params'] = flat[m.table_elems + off: m.table_elems + off + n]
+            return out
+        va, vs = views(self.exp_avg), views(self.exp_avg_sq)
+        steps = set()
+        for k, name in zip(keys, names):
+            va[name].copy_(state[k]['exp_avg'].reshape(va[name].shape))
+            vs[name].copy_(state[k]['exp_avg_sq'].reshape(vs[name].shape))
+            steps.add(int(state[k]['step']))
+        self.step_count = max(steps) if steps else 0
+        self.param_groups[0]['lr'] = optim_sd['param_groups'][0].get('lr', self.lr)
+        self.param_groups[0]['initial_lr'] = optim_sd['param_groups'][0].get('initial_lr', self.param_groups[0]['initial_lr'])
+        if ema_sd is not None and self.ema is not None and ema_sd.get('shadow_params') is not None:
+            ve = views(self.ema)
+            order = ['x_density_embedder.embeddings', 'x_color_embedder.embeddings'] + [name + '.params' for (name, _, _) in MLP_LAYOUT]
+            for name, t in zip(order, ema_sd['shadow_params']):
+                ve[name].copy_(t.reshape(ve[name].shape))
+            self.ema_updates = int(ema_sd.get('num_updates') or 0)
+
     def load_state_dict(self, sd):
+        if 'param_groups' in sd and 'state' in sd:
+            return self.load_reference_state(sd)
         self.step_count = sd['step']
         self.exp_avg.copy_(sd['exp_avg'])
         self.exp_avg_sq.copy_(sd['exp_avg_sq'])

@@ -473,6 +473,127 @@ def test_sparsity_term_sigma_only_forward_backward(O, dev):
     assert torch.isfinite(m.arena.grad).all() and float(m.arena.grad[:m.table_elems].view(m.rows, 2, 2)[:, 1].abs().max()) > 0
 
 
+def test_fern_cameras_step_with_sparsity_term(O, dev):
+    """BASELINE config 4 on its own cameras (nerfstyle_amd/assets/llff_fern_cameras.json, from the reference's
+    datasets/nerf_llff_data/fern/transforms_train.json): a training render of 4 096 fern rays against the oracle pipeline on
+    the same rays (PSNR > 45 dB), then the step's loss = fused reconstruction loss + the sparsity term
+    (trainers/base.py:285-291,409-413, --sparsity_lambda 0.01) back-propagated together: the gradient equals the sum of the
+    two terms' separate gradients (the sparsity term reaches the density table and density_net only)."""
+    from nerfstyle_amd.common import BBox
+    from nerfstyle_amd.config import NetworkConfig, RendererConfig
+    from nerfstyle_amd.recon_loss import recon_loss
+    from nerfstyle_amd.renderer import Renderer
+    from nerfstyle_amd.scene import load_cameras
+    from nerfstyle_amd.style_nerf import MLP_LAYOUT, StyleTCNerf
+    from oracle import torch_port as TP
+    nc = 5
+    ref = TP.Field(num_classes=nc, table_scale=0.5)
+    m = StyleTCNerf(NetworkConfig(), BBox.from_radius(2.0), nc, enc_dtype=torch.float32, use_dir=False)
+    sd = m.state_dict()
+    sd.update({'x_density_embedder.embeddings': ref.emb_density.detach(), 'x_color_embedder.embeddings': ref.emb_color.detach(),
+               'density_net.params': ref.p_density.detach(), 'color1_net.params': ref.p_color1.detach(),
+               'color2_net.params': ref.p_color2.detach(), 'class_net.params': ref.p_class.detach()})
+    m.load_state_dict(sd)
+    poses, intr, meta = load_cameras('fern')
+    assert len(poses) == 17 and abs(intr.fx - 407.5657916100737) < 1e-9
+    r = Renderer(m, RendererConfig.llff(), intr, 2.0, raymarch_channels=3 + nc).to(dev)
+    grid, bits = small_scene()
+    r.density_grid = torch.tensor(grid, device=dev)
+    r.density_bitfield = torch.tensor(bits, device=dev)
+    r.update_occ = False
+    rng = np.random.default_rng(17)
+    pix = rng.choice(intr.w * intr.h, 4096, replace=False)
+    ro, rd = O.generate_rays(poses[5], intr.w, intr.h, intr.fx, intr.fy, intr.cx, intr.cy, 3, pix_indices=pix)
+    rgb_o, d_o, cls_o, cnt = _oracle_render(O, ref, bits, ro, rd)
+    assert cnt > 4096 * 8
+    pose, pix_t = torch.tensor(poses[5], device=dev), torch.tensor(pix, device=dev)
+    g = torch.Generator().manual_seed(2)
+    t_rgb = torch.rand(intr.w * intr.h, 3, generator=g).to(dev)
+    t_cls = torch.randint(0, nc, (intr.w * intr.h,), generator=g).to(dev)
+    pts = (torch.rand(50000, 3, generator=g) * 4.0 - 2.0).to(dev)
+    SCALE = 4096.0
+
+    def step(with_render, with_sparsity):
+        m._ensure_grad().zero_()
+        total = 0.0
+        out = None
+        if with_render:
+            out = r.render(pose, None, training=True, pix_subset=pix_t)
+            total = recon_loss(out['rgb_map'], out['classes'], t_rgb, t_cls, pix_t, ce_lambda=1e-3, factor=SCALE)
+        if with_sparsity:
+            sig = m(pts)
+            total = total + torch.mean(torch.abs(1 - torch.exp(-0.05 * sig))) * 0.01 * SCALE
+        total.backward()
+        return m.arena.grad.detach().clone() / SCALE, out
+    g_both, out = step(True, True)
+    rgb = out['rgb_map'].detach().cpu().numpy()
+    assert O.compute_psnr(float(np.mean((rgb - rgb_o) ** 2))) > 45.0
+    g_r, _ = step(True, False)
+    g_s, _ = step(False, True)
+    assert float(g_r.abs().sum()) > 0 and float(g_s.abs().sum()) > 0
+    assert rel_l2((g_r + g_s).cpu().numpy(), g_both.cpu().numpy()) < 2e-5
+    gt = g_s[:m.table_elems].view(m.rows, 2, 2)
+    assert float(gt[:, 1].abs().max()) == 0.0 and float(gt[:, 0].abs().max()) > 0.0
+    for name, off, n in MLP_LAYOUT:
+        blk = g_s[m.table_elems + off: m.table_elems + off + n]
+        assert (float(blk.abs().max()) > 0.0) == (name == 'density_net'), name
+
+
+def test_checkpoint_roundtrip_on_the_gpu_is_bit_identical(O, dev, tmp_path):
+    """Save (nerfstyle_amd.checkpoint, the reference's key layout) after 5 training steps with occupancy updates, device-side
+    GradScaler and EMA; restore into freshly constructed objects; the restored renderer renders the same image bit for bit
+    and the NEXT training step (same pixels) leaves bit-identical parameters, moments, EMA and scaler state."""
+    from nerfstyle_amd import checkpoint as C
+    from nerfstyle_amd.common import BBox
+    from nerfstyle_amd.config import NetworkConfig, RendererConfig
+    from nerfstyle_amd.optim import FusedAdam, LossScaler
+    from nerfstyle_amd.recon_loss import recon_loss
+    from nerfstyle_amd.renderer import Renderer
+    from nerfstyle_amd.scene import load_room_cameras
+    from nerfstyle_amd.style_nerf import StyleTCNerf
+    poses, intr, _ = load_room_cameras()
+    nc = 4
+
+    def build():
+        torch.manual_seed(0)
+        m = StyleTCNerf(NetworkConfig(), BBox.from_radius(2.0), nc, enc_dtype=None, use_dir=False)
+        r = Renderer(m, RendererConfig.llff(), intr, 2.0, raymarch_channels=3 + nc, samples_per_ray_cap=512).to(dev).manual_seed(9)
+        return m, r, FusedAdam(m, lr=1e-2, ema_decay=0.95), LossScaler(init_scale=8192.0, growth_interval=4)
+    m, r, opt, sc = build()
+    g = torch.Generator().manual_seed(6)
+    npix = intr.w * intr.h
+    t_rgb = torch.rand(npix, 3, generator=g).to(dev)
+    t_cls = torch.randint(0, nc, (npix,), generator=g).to(dev)
+    pixs = [torch.randperm(npix, generator=g)[:4096].to(dev) for _ in range(6)]
+    pose = torch.tensor(poses[3], device=dev)
+
+    def train_step(m, r, opt, sc, pix):
+        out = r.render(pose, None, training=True, pix_subset=pix)
+        recon_loss(out['rgb_map'], out['classes'], t_rgb, t_cls, pix, scale=sc.scale_tensor(dev)).backward()
+        sc.step(opt, lr_decay_steps=100.0)
+    for it in range(5):
+        train_step(m, r, opt, sc, pixs[it])
+    f = tmp_path / 'iter_0005.pth'
+    C.save_checkpoint(f, r, optim=opt, scaler=sc, iter_ctr=5)
+    m2, r2, opt2, sc2 = build()
+    assert C.restore(C.load_checkpoint(f), r2, optim=opt2, scaler=sc2) == 5
+    assert sc2.get_scale() == sc.get_scale() == 16384.0 and opt2.step_count == 5       # grew once after 4 clean steps
+    eval_pix = torch.arange(0, npix, 37, device=dev)
+    with torch.no_grad():
+        a = r.render(pose, None, training=False, pix_subset=eval_pix)
+        b = r2.render(pose, None, training=False, pix_subset=eval_pix)
+    assert torch.equal(a['rgb_map'], b['rgb_map']) and torch.equal(a['classes'], b['classes'])
+    assert torch.equal(r.density_bitfield, r2.density_bitfield) and r2.local_step == r.local_step == 5
+    assert torch.equal(m.arena.detach(), m2.arena.detach()) and torch.equal(opt.exp_avg, opt2.exp_avg)
+    assert torch.equal(opt.exp_avg_sq, opt2.exp_avg_sq) and torch.equal(opt.ema, opt2.ema) and opt2.ema_updates == opt.ema_updates
+    train_step(m, r, opt, sc, pixs[5])
+    train_step(m2, r2, opt2, sc2, pixs[5])
+    # the table gradient is summed by float atomics in arrival order: a step is reproducible to fp32 rounding, not bit for bit
+    d = (m.arena.detach() - m2.arena.detach()).abs()
+    assert float((d > 1e-5).float().mean()) < 1e-3 and sc.state_dict() == sc2.state_dict()
+    assert float((opt.exp_avg - opt2.exp_avg).abs().max()) < 1e-6 * max(1.0, float(opt.exp_avg.abs().max()))
+
+
 def test_deferred_backprop_equals_direct_and_trains_only_colour_table(O, dev):
     """Stylisation glue (trainers/style.py:162-204): per-patch deferred back-propagation gives the
     gradient of one direct full-frame backward; with OPTIM_KEYS = ['x_color_embedder'] (style.py:25)

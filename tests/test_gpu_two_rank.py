@@ -68,6 +68,61 @@ print("CHILD_OK", rank, world)
 '''
 
 
+CHILD_STYLE = r'''
+import os, sys
+sys.path.insert(0, os.environ["NSR_ROOT"])
+import torch
+from nerfstyle_amd import parallel as P
+torch.cuda.set_device(0)
+os.environ["NSR_BENCH_DEVICE"] = "0"
+rank, local_rank, world = P.init(backend="gloo", seed=78)
+dev = torch.device("cuda", 0)
+from nerfstyle_amd import raymarching
+from nerfstyle_amd.common import BBox, Intrinsics
+from nerfstyle_amd.config import NetworkConfig, RendererConfig
+from nerfstyle_amd.optim import FusedAdam, LossScaler
+from nerfstyle_amd.renderer import Renderer
+from nerfstyle_amd.scene import load_room_cameras, synthetic_density_grid
+from nerfstyle_amd.style_nerf import StyleTCNerf
+from nerfstyle_amd.stylize import deferred_backprop_step
+nc = 5
+model = StyleTCNerf(NetworkConfig(), BBox.from_radius(2.0), nc, enc_dtype=None, use_dir=False)
+with torch.no_grad():
+    model.arena[:model.table_elems].uniform_(-0.5, 0.5)
+    model.arena.add_(0)
+poses, _, _ = load_room_cameras()
+# 181 x 135 frame: an ODD number of pixel rows (pass 1 splits 68 / 67: the ragged all-gather) and 3 x 3 patches of 64 (5 / 4)
+intr = Intrinsics(h=135, w=181, fx=137.0, fy=137.0, cx=90.5, cy=67.5)
+cfg = RendererConfig.llff()
+cfg.max_steps = 512
+r = Renderer(model, cfg, intr, 2.0, raymarch_channels=3 + nc, samples_per_ray_cap=256).to(dev)
+r.density_grid = torch.tensor(synthetic_density_grid(2.0, 128, 48, 0), device=dev)
+r.density_bitfield = raymarching.packbits(r.density_grid, 0.5)
+r.update_occ = False                                    # StyleTrainer never updates the grid
+opt = FusedAdam(model, lr=0.1, keywords=["x_color_embedder"])
+scaler = LossScaler(init_scale=1024.0)
+W, H = intr.size()
+g = torch.Generator().manual_seed(4)
+tgt = torch.rand(H, W, 3, generator=g).to(dev)
+
+def image_loss(rgb, classes):
+    # any image-space loss: MSE to a target + a neighbour-difference term + a use of the class logits' argmax (style.py:85)
+    pred = torch.argmax(classes, dim=-1)
+    wgt = 1.0 + 0.1 * pred.float().unsqueeze(-1)
+    return torch.mean(wgt * (rgb - tgt) ** 2) + 0.1 * torch.mean((rgb[1:] - rgb[:-1]) ** 2)
+
+pose = torch.tensor(poses[1], device=dev)
+loss, rgb = deferred_backprop_step(r, pose, image_loss, patch_size=64, loss_scale=scaler.scale_tensor(dev), rank=rank, world=world,
+                                   optimizer=opt, with_classes=True)
+grad = (model.arena.grad.detach() / 1024.0).cpu()
+opt.step(scaler=scaler)
+torch.cuda.synchronize()
+torch.save({"grad": grad, "rgb": rgb.cpu(), "loss": loss.cpu(), "arena": model.arena.detach().cpu()}, os.environ["NSR_OUT"])
+P.barrier()
+print("CHILD_OK", rank, world)
+'''
+
+
 def _free_port():
     s = socket.socket()
     s.bind(('127.0.0.1', 0))
@@ -125,3 +180,32 @@ def test_two_ranks_on_one_gpu_keep_identical_replicas(tmp_path):
     assert f5 < 0.1 and f3 < 2e-3 and rel_arena < 2e-2, (f5, f3, rel_arena)
     moved = float((one['arena'] - one['ema']).abs().max())
     assert moved > 1e-4                                        # the three steps did train
+
+
+def test_two_ranks_stylisation_iteration_equals_one_rank(tmp_path):
+    """One iteration of the deferred back-propagation (trainers/style.py:162-204 as sharded by stylize.py) at world = 2 on one
+    card: pass 1 split by pixel rows with an ODD row count (the ragged all-gather branch), 9 patches split 5 / 4, the
+    colour-table gradient packed and all-reduced (derived from the optimiser: FusedAdam(keywords=['x_color_embedder'])),
+    device-side GradScaler step -- against the same iteration in one process."""
+    assert torch.cuda.is_available()
+    script = tmp_path / 'child_style.py'
+    script.write_text(CHILD_STYLE)
+    two = _run(script, 2, tmp_path, 's2')
+    one = _run(script, 1, tmp_path, 's1')[0]
+    a, b = two
+    n_tab = 6299960 * 4
+    # pass 1: every rank holds the same full frame, equal to the single-process frame (same kernels, same samples per ray)
+    assert torch.equal(a['rgb'], b['rgb']) and float((a['rgb'] - one['rgb']).abs().max()) < 1e-6
+    assert abs(float(a['loss']) - float(one['loss'])) < 1e-6 * abs(float(one['loss']))
+    ga, gb, g1 = (x['grad'][:n_tab].view(-1, 2, 2) for x in (a, b, one))
+    assert torch.equal(ga[:, 1], gb[:, 1])                                   # the reduced colour-table gradient: identical replicas
+    assert float(g1[:, 1].abs().sum()) > 0 and float(g1[:, 0].abs().max()) == 0.0
+    rel = float((ga[:, 1].double() - g1[:, 1].double()).norm() / g1[:, 1].double().norm())
+    assert rel < 1e-5, rel
+    # the optimiser step (colour table only) keeps the replicas identical and changes nothing else
+    assert torch.equal(a['arena'], b['arena'])
+    ta, t1 = a['arena'][:n_tab].view(-1, 2, 2), one['arena'][:n_tab].view(-1, 2, 2)
+    assert torch.equal(ta[:, 0], t1[:, 0]) and torch.equal(a['arena'][n_tab:], one['arena'][n_tab:])
+    assert float((ta[:, 1] - t1[:, 1]).abs().max()) <= 0.2 + 1e-6             # Adam step 1: |delta| = lr per touched entry
+    assert float(((ta[:, 1] - t1[:, 1]).abs() > 1e-3).float().mean()) < 1e-3
+

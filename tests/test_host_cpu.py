@@ -127,6 +127,111 @@ def test_checkpoint_layout_roundtrip_and_refusal(tmp_path):
         C.load_checkpoint(bad)
 
 
+def test_reference_written_checkpoint_is_ingested_without_executing_it(tmp_path):
+    """A file in the REFERENCE's own layout (trainers/base.py:231-249: pickled config.* dataclasses incl. the nested
+    HashGridConfig / TrainIntervalConfig, common.Intrinsics inside `renderer`, pathlib.PosixPath, torch.optim.Adam /
+    GradScaler / torch_ema state dicts) loads through nerfstyle_amd.reference_schema's inert stand-ins on the weights-only
+    allow-list: the file below is pickled from classes registered as `config.*` / `common.Intrinsics` exactly as the reference's
+    are, then read back with those modules GONE from sys.modules (nothing is imported, nothing from the file runs).
+    A file that names any other global is still refused."""
+    import pathlib
+    import sys
+    import types
+    import pytest
+    from nerfstyle_amd import checkpoint as C
+    from nerfstyle_amd import reference_schema as RS
+    from nerfstyle_amd.common import BBox, Intrinsics
+    from nerfstyle_amd.config import NetworkConfig, PosEncConfig, RendererConfig
+    from nerfstyle_amd.optim import FusedAdam, LossScaler
+    from nerfstyle_amd.renderer import Renderer
+    from nerfstyle_amd.style_nerf import MLP_LAYOUT, StyleTCNerf
+    intr = Intrinsics(378, 504, 383.8, 383.8, 252., 189.)
+    ncfg = NetworkConfig(pos_enc=PosEncConfig(hashmap_size=14))          # small tables: the layout is what is tested
+    m = StyleTCNerf(ncfg, BBox.from_radius(2.0), 5)
+    r = Renderer(m, RendererConfig.llff(), intr, 2.0, raymarch_channels=8)
+    with torch.no_grad():
+        m.arena.uniform_(-1, 1)
+    r.density_grid[1, 5:50] = 2.0
+    r.local_step, r.mean_count = 33, 77
+
+    def mk(path, **kw):
+        o = RS.STANDINS[path].__new__(RS.STANDINS[path])
+        o.__dict__.update(kw)
+        return o
+    names = [n for n, _ in m.named_views()]
+    g = torch.Generator().manual_seed(3)
+    adam_state = {i: {'step': torch.tensor(41.), 'exp_avg': torch.randn(v.shape, generator=g), 'exp_avg_sq': torch.rand(v.shape, generator=g)}
+                  for i, (n, v) in enumerate(m.named_views())}
+    shadow = [torch.randn(v.shape, generator=g) for _, v in m.named_views()]
+    rs = r.state_dict()
+    rs['intr'] = mk('common.Intrinsics', h=378, w=504, fx=383.8, fy=383.8, cx=252., cy=189.)
+    rs['model'] = dict(rs['model'], **{'x_density_embedder.offsets': torch.zeros(17, dtype=torch.int32)})   # a buffer the reference saves
+    ref_sd = {
+        'version': 'deadbeef', 'log_dir': pathlib.Path('/runs/room'), 'iter_ctr': 41,
+        'cfg': mk('config.BaseConfig', log_dir=pathlib.Path('runs/room'), data_cfg=pathlib.Path('cfgs/dataset/llff_room.yaml'), ckpt=None),
+        'dataset_cfg': mk('config.DatasetConfig', root_path=pathlib.Path('datasets/nerf_llff_data/room'), type='llff', bound=2.0, scale=0.33,
+                          replica_cfg=mk('config.DatasetConfig.ReplicaConfig', name='room_0', focal_ratio=0.5, traj_ids=[1, 2], black2white=True)),
+        'train_cfg': mk('config.TrainConfig', num_rays_per_batch=4096, enable_amp=True,
+                        intervals=mk('config.TrainConfig.TrainIntervalConfig', print=100, log=100, ckpt=5000, test=5000)),
+        'net_cfg': mk('config.NetworkConfig', network_seed=80000, density_out_dims=16,
+                      pos_enc=mk('config.NetworkConfig.HashGridConfig', n_lvls=16, n_feats_per_lvl=2, hashmap_size=19, min_res=16, max_res_coeff=1024.0)),
+        'render_cfg': mk('config.RendererConfig', grid_size=128, max_steps=1024, t_thresh=1e-4),
+        'renderer': rs,
+        'optim': {'state': adam_state, 'param_groups': [{'lr': 0.0097, 'initial_lr': 0.01, 'betas': (0.9, 0.999), 'eps': 1e-15,
+                                                        'params': list(range(len(names)))}]},
+        'scheduler': {'base_lrs': [0.01], 'last_epoch': 41, 'lr_lambdas': [None]},
+        'scaler': {'scale': 32768.0, 'growth_factor': 2.0, 'backoff_factor': 0.5, 'growth_interval': 2000, '_growth_tracker': 12},
+        'ema': {'decay': 0.95, 'num_updates': 41, 'shadow_params': shadow, 'collected_params': None},
+    }
+    cfgm, comm = types.ModuleType('config'), types.ModuleType('common')
+    for path, cls in RS.STANDINS.items():
+        mod, _, q = path.partition('.')
+        if '.' not in q:
+            setattr(cfgm if mod == 'config' else comm, q, cls)
+    keep = {k: sys.modules.get(k) for k in ('config', 'common')}
+    sys.modules['config'], sys.modules['common'] = cfgm, comm
+    f = tmp_path / 'iter_00041.pth'
+    try:
+        torch.save(ref_sd, f)                         # pickles `config.NetworkConfig`, `common.Intrinsics`, `pathlib.PosixPath`, getattr(...)
+    finally:
+        for k, v in keep.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+    raw = open(f, 'rb').read()
+    assert b'config' in raw and b'HashGridConfig' in raw and b'PosixPath' in raw and b'Intrinsics' in raw
+    with pytest.raises(Exception):
+        torch.load(f, weights_only=True)               # refused without the allow-list
+    sd = C.load_checkpoint(f)
+    assert 'config' not in sys.modules or sys.modules['config'] is keep['config']
+    assert sd['log_dir'] == '/runs/room' and sd['cfg']['data_cfg'] == 'cfgs/dataset/llff_room.yaml'
+    assert sd['net_cfg']['pos_enc'] == {'__dataclass__': 'HashGridConfig', 'n_lvls': 16, 'n_feats_per_lvl': 2, 'hashmap_size': 19,
+                                        'min_res': 16, 'max_res_coeff': 1024.0}
+    assert sd['train_cfg']['intervals']['ckpt'] == 5000 and sd['dataset_cfg']['replica_cfg']['traj_ids'] == [1, 2]
+    assert sd['renderer']['intr']['__dataclass__'] == 'Intrinsics'
+    m2 = StyleTCNerf(ncfg, BBox.from_radius(2.0), 5)
+    r2 = Renderer(m2, RendererConfig.llff(), intr, 2.0, raymarch_channels=8)
+    opt2 = FusedAdam(m2, lr=1e-2, ema_decay=0.95)
+    sc2 = LossScaler()
+    assert C.restore(sd, r2, optim=opt2, scaler=sc2) == 41
+    assert torch.equal(m2.arena.detach(), m.arena.detach()) and torch.equal(r2.density_grid, r.density_grid)
+    assert r2.local_step == 33 and r2.mean_count == 77
+    va = opt2.exp_avg[:m2.table_elems].view(m2.rows, 2, 2)
+    assert torch.equal(va[:, 0, :], adam_state[0]['exp_avg']) and torch.equal(va[:, 1, :], adam_state[1]['exp_avg'])
+    name, off, n = MLP_LAYOUT[2]
+    assert torch.equal(opt2.exp_avg_sq[m2.table_elems + off: m2.table_elems + off + n], adam_state[4]['exp_avg_sq'].reshape(-1))
+    assert torch.equal(opt2.ema[:m2.table_elems].view(m2.rows, 2, 2)[:, 1, :], shadow[1])
+    assert opt2.step_count == 41 and opt2.ema_updates == 41 and abs(opt2.param_groups[0]['lr'] - 0.0097) < 1e-12
+    st = sc2.state_dict()
+    assert st['scale'] == 32768.0 and st['_growth_tracker'] == 12 and st['steps'] == 41
+    # anything outside the schema is still refused
+    bad = tmp_path / 'evil.pth'
+    torch.save({'x': types.SimpleNamespace(a=1)}, bad)
+    with pytest.raises(RuntimeError, match='nothing from a checkpoint file is executed'):
+        C.load_checkpoint(bad)
+
+
 def test_resident_dataset_targets():
     """nerfstyle_amd/dataset.py: per-pixel target rows (RGB + segment id) and poses resident on the device,
     gathered by pixel id -- the rows nerf_lib.generate_rays hands to calc_loss (nerf_lib.py:126-141)."""
