@@ -154,12 +154,18 @@ __global__ void __launch_bounds__(OCC_BLOCK)
 k_occ_fill(float *__restrict__ tmp, uint32_t n, float v) {
     for (uint32_t i = blockIdx.x * OCC_BLOCK + threadIdx.x; i < n; i += gridDim.x * OCC_BLOCK) tmp[i] = v;
 }
-// tmp_grid[cas, indices] = sigmas (renderer.py:160,181); duplicates: one of the writers wins, as with index_put_
+// tmp_grid[cas, indices] = sigmas (renderer.py:160,181).  A partial update draws cells WITH replacement (H^3/4 uniform draws plus
+// the occupied half), so a cell can be written several times; the reference's index_put_ lets any of the writers win.  Here the
+// LARGEST density wins -- one of the legal outcomes, and the same one on every run and every rank (sigma >= 0: the bit pattern
+// of a non-negative float orders like the float, and beats the -1 the buffer was filled with)
 __global__ void __launch_bounds__(OCC_BLOCK)
 k_occ_scatter(const float *__restrict__ sigmas, const int32_t *__restrict__ indices, uint32_t P, float *__restrict__ tmp) {
     for (uint32_t p = blockIdx.x * OCC_BLOCK + threadIdx.x; p < P; p += gridDim.x * OCC_BLOCK) {
         const int32_t f = indices[p];
-        if (f >= 0) tmp[f] = sigmas[p];
+        if (f < 0) continue;
+        const float s = sigmas[p];
+        if (s >= 0.0f) atomicMax(reinterpret_cast<int *>(tmp) + f, __float_as_int(s));
+        else tmp[f] = s;                         // negative or NaN: never produced by the field (exp * density_scale)
     }
 }
 // renderer.py:183-186: grid = max(grid * decay, tmp) where both are >= 0; block sums of clamp(grid, 0)

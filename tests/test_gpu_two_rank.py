@@ -36,7 +36,11 @@ from nerfstyle_amd.style_nerf import StyleTCNerf
 nc = 5
 model = StyleTCNerf(NetworkConfig(), BBox.from_radius(2.0), nc, enc_dtype=None, use_dir=False)
 poses, intr, _ = load_room_cameras()
-r = Renderer(model, RendererConfig.llff(), intr, 2.0, raymarch_channels=3 + nc, samples_per_ray_cap=1024).to(dev).manual_seed(5)
+cfg = RendererConfig.llff()
+if os.environ.get("NSR_PARTIAL_UPDATES"):
+    cfg.update_iter, cfg.update_thres = 1, 1            # step 0: full update; steps 1, 2: PARTIAL updates (cells drawn with
+                                                        # replacement -- duplicates resolve to the largest density on every rank)
+r = Renderer(model, cfg, intr, 2.0, raymarch_channels=3 + nc, samples_per_ray_cap=1024).to(dev).manual_seed(5)
 assert r.update_occ                                     # occupancy from the model itself, every rank draws the same cells
 opt = FusedAdam(model, lr=1e-2, ema_decay=0.95)
 g = torch.Generator().manual_seed(3)
@@ -131,12 +135,13 @@ def _free_port():
     return p
 
 
-def _run(script, world, tmp_path, tag):
+def _run(script, world, tmp_path, tag, extra_env=None):
     port = _free_port()
     procs, outs = [], []
     for rank in range(world):
         env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1',
-                   MASTER_PORT=str(port), NSR_ROOT=ROOT, NSR_OUT=str(tmp_path / '{}_{}.pt'.format(tag, rank)), OMP_NUM_THREADS='2')
+                   MASTER_PORT=str(port), NSR_ROOT=ROOT, NSR_OUT=str(tmp_path / '{}_{}.pt'.format(tag, rank)), OMP_NUM_THREADS='2',
+                   **(extra_env or {}))
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
                                       text=True))
     for p in procs:
@@ -180,6 +185,12 @@ def test_two_ranks_on_one_gpu_keep_identical_replicas(tmp_path):
     assert f5 < 0.1 and f3 < 2e-3 and rel_arena < 2e-2, (f5, f3, rel_arena)
     moved = float((one['arena'] - one['ema']).abs().max())
     assert moved > 1e-4                                        # the three steps did train
+    # partial occupancy updates (steps 1 and 2 of a run with update_iter = update_thres = 1): cells are drawn with replacement,
+    # a duplicate resolves to the largest density -- not to whichever writer came last -- so the replicas' grids stay bit-identical
+    pa, pb = _run(script, 2, tmp_path, 'p2', {'NSR_PARTIAL_UPDATES': '1'})
+    for k in ('arena', 'ema', 'bitfield', 'grid'):
+        assert torch.equal(pa[k], pb[k]), k
+    assert not torch.equal(pa['grid'], a['grid'])              # the partial updates did change the grid
 
 
 def test_two_ranks_stylisation_iteration_equals_one_rank(tmp_path):
