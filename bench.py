@@ -353,8 +353,17 @@ def run_recon(args, dev, rank, world):
         perm_state['pos'] = p0 + n_rays
         return perm_state['perm'][p0:p0 + n_rays]
 
+    # N > 1: the parameter-independent front of step i+1 (ray generation, march, compaction, sample sort: Renderer.begin_train)
+    # is issued while the gradient all-reduce of step i is in flight (parallel.sync_gradients_async); N == 1: no overlap, no
+    # side stream, steps run back to back
+    nxt, pending = {}, {}
+    last_it = args.warmup + args.steps - 1
+
     def inputs(it):
-        return poses[(it * 7 + rank) % poses.shape[0]], draw_pixels()
+        if it not in nxt:
+            nxt.clear()
+            nxt[it] = (poses[(it * 7 + rank) % poses.shape[0]], draw_pixels())
+        return nxt[it]
 
     def step(it):
         pose, pix = inputs(it)
@@ -362,12 +371,18 @@ def run_recon(args, dev, rank, world):
             loss = graphed(pose, pix)
             cnt = r._last_counter
         else:
-            out = r.render(pose, None, training=True, pix_subset=pix)
+            ctx = pending.pop(it, None)
+            if ctx is None:
+                ctx = r.begin_train(pose, pix)
+            out = r.finish_train(ctx)
             cnt = r._last_counter           # this render's device-side sample count
             loss = loss_fn(out, pix)
             loss.backward()
         if world > 1:
-            P.sync_gradients(model, optimizer=opt)
+            sync = P.sync_gradients_async(model, optimizer=opt)
+            if graphed is None and it < last_it and not r.occupancy_update_due():
+                pending[it + 1] = r.begin_train(*inputs(it + 1))
+            sync.wait()
         if scaler is not None:
             opt.step(scaler=scaler, lr_decay_steps=30000)      # lr = 1e-2 * 0.1^(steps / 30000), on the device
         else:

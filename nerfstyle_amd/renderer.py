@@ -199,7 +199,7 @@ class Renderer(torch.nn.Module):
     def render_train(self, rays: RayBatch, **kwargs):
         """renderer.py:196-235 -> (image [N,3], depth [N], classes [N,nc]).  Three stages that graph.GraphedPatchBackward
         also drives one by one: march (sync-free), optional spatial order of the samples, shade (field + composite)."""
-        if self.update_occ and (self.local_step % self.cfg.update_iter == 0):
+        if self.occupancy_update_due():
             self.update_state()
         mt = self.march_train(rays)
         perm = None
@@ -321,6 +321,33 @@ class Renderer(torch.nn.Module):
         image = image + (1 - weights_sum).unsqueeze(-1)
         depth = torch.clamp(depth - nears, min=0) / (fars - nears)
         return image, depth, classes
+
+    # ---- a training render in two halves (data-parallel overlap, parallel.py) ---------------------------------------
+    def occupancy_update_due(self) -> bool:
+        """The next training render starts with update_state (renderer.py:206-207): it reads the parameters."""
+        return bool(self.update_occ and (self.local_step % self.cfg.update_iter == 0))
+
+    def begin_train(self, pose, pix_subset, dense: bool = False) -> dict:
+        """First half of render(pose, training=True, pix_subset=...): ray generation, [occupancy update when due,] occupancy
+        march + compaction and the spatial order of the samples.  Apart from the occupancy update none of it reads the
+        PARAMETERS (the march reads the bitfield only), so a data-parallel step may issue it for step i+1 while the gradient
+        all-reduce of step i is in flight and the optimiser has not stepped yet -- as long as occupancy_update_due() is
+        False.  finish_train(ctx) does the rest."""
+        rays, _ = generate_rays(pose, self.intr, None, camera_flip=self.cfg.flip_camera, pix_subset=pix_subset, device=self.device)
+        if self.occupancy_update_due():
+            self.update_state()
+        mt = self.march_train(rays)
+        perm = None
+        if torch.is_grad_enabled() and self._use_spatial_order(mt['N'], dense):
+            perm = self.model.sample_order(mt['xyzs'], mt['counter'])
+        return {'mt': mt, 'perm': perm}
+
+    def finish_train(self, ctx: dict) -> Dict[str, torch.Tensor]:
+        """Second half: fused field + composite + epilogue on the samples begin_train marched (reads the parameters)."""
+        out = {'target': None}
+        out['rgb_map'], out['trans_map'], out['classes'] = self.shade_train(ctx['mt'], ctx['perm'])
+        self._last_counter, self._last_capacity = ctx['mt']['counter'], ctx['mt']['M']
+        return out
 
     def render(self, pose, image=None, patch: Optional[Box2D] = None, num_rays: Optional[int] = None,
                training: bool = False, pix_subset=None, dense: Optional[bool] = None) -> Dict[str, torch.Tensor]:

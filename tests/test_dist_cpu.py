@@ -56,6 +56,20 @@ assert torch.equal(t4[:, 1], torch.arange(24.).view(6, 2, 2)[:, 1] * 3)      # s
 assert torch.equal(t4[:, 0], b4[:, 0]) and torch.equal(m.g[24:], before[24:]) # everything else untouched
 m2 = M(); P.sync_gradients(m2)
 assert torch.equal(m2.g, torch.arange(29.) * 3)
+# what is reduced follows from what the optimiser trains; the async form returns a handle, other work can be issued, wait() ends it
+class Opt:
+    def __init__(self, mask, nets): self.table_mask, self.nets = mask, nets
+m3 = M(); before = m3.g.clone()
+h = P.sync_gradients_async(m3, optimizer=Opt(0xC, []), buckets=2)      # colour table only: packed, two buckets
+busy = torch.ones(1000).sum()                                             # (stands for the next step's march)
+h.wait()
+t3 = m3.g[:24].view(6, 2, 2)
+assert torch.equal(t3[:, 1], torch.arange(24.).view(6, 2, 2)[:, 1] * 3) and torch.equal(t3[:, 0], before[:24].view(6, 2, 2)[:, 0])
+assert torch.equal(m3.g[24:], before[24:])
+m4 = M(); h = P.sync_gradients_async(m4, optimizer=Opt(0xF, [(0, 5)]), buckets=3); h.wait()
+assert torch.equal(m4.g, torch.arange(29.) * 3)                          # tables + a net trained: the whole arena
+m5 = M(); P.sync_gradients(m5, optimizer=Opt(0x3, []))                   # density table only
+assert torch.equal(m5.g[:24].view(6, 2, 2)[:, 0], torch.arange(24.).view(6, 2, 2)[:, 0] * 3)
 # identical default-generator streams after init(seed=...)
 P.init(backend="gloo", seed=1234)
 r = torch.rand(4); rs = [torch.zeros(4) for _ in range(world)]

@@ -52,15 +52,23 @@ b, e = P.shard_bounds(pix_all.numel(), rank, world)
 pix = pix_all[b:e]
 SCALE = 65536.0
 pose = torch.tensor(poses, device=dev)
+ctx = None
 for it in range(3):
-    out = r.render(pose[it], None, training=True, pix_subset=pix)
+    # the data-parallel step of bench.py: the march + sample order of step it+1 (parameter-independent) are issued while the
+    # all-reduce of step it is in flight; never across an occupancy update
+    if ctx is None:
+        ctx = r.begin_train(pose[it], pix)
+    out = r.finish_train(ctx)
+    ctx = None
     # sums normalised by the GLOBAL ray count: the summed gradient equals the single-process gradient
     mse = ((out["rgb_map"] - target[pix]) ** 2).sum() / (3 * pix_all.numel())
     lg = out["classes"]
     ce = (torch.logsumexp(lg, 1) - lg.gather(1, tcls[pix][:, None])[:, 0]).sum() / pix_all.numel() * 1e-3
     ((mse + ce) * SCALE).backward()
-    if world > 1:
-        P.sync_gradients(model)
+    sync = P.sync_gradients_async(model, optimizer=opt, buckets=3)
+    if it < 2 and not r.occupancy_update_due():
+        ctx = r.begin_train(pose[it + 1], pix)
+    sync.wait()
     if it == 0:
         grad0 = (model.arena.grad.detach() / SCALE).cpu()
     opt.step(grad_scale=SCALE)
