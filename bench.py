@@ -525,7 +525,8 @@ def run_recon(args, dev, rank, world):
         'config': {
             'workload': wl, 'rays_per_step_per_gpu': n_rays, 'samples_per_ray': round(spr, 2), 'max_steps': rcfg.max_steps,
             'num_classes': nc, 'table_dtype': args.table_dtype, 'mfma_dtype': args.compute_dtype,
-            'params': int(model.arena.numel()), 'parallelism': 'rays sharded x{} + RCCL all-reduce'.format(world),
+            'params': int(model.arena.numel()), 'parallelism': 'rays sharded x{} + RCCL all-reduce'.format(world) + (
+                " (async, overlapped with the next step's march + sample sort)" if world > 1 and graphed is None else ''),
             'occupancy_updates_in_timed_region': occ_updates,
             'occupancy': ('device-side update every {} steps inside the step (full update: {} sigma queries); the march reads the seeded '
                           'synthetic bitfield (random-init model has no scene)'.format(rcfg.update_iter, r.cascade * rcfg.grid_size ** 3)
