@@ -338,7 +338,10 @@ def run_recon(args, dev, rank, world):
     if args.graph:
         assert sp_lambda == 0, 'the sparsity term draws fresh points from a torch generator every step: not part of the captured step'
         from nerfstyle_amd.graph import GraphedRenderStep
-        graphed = GraphedRenderStep(r, n_rays, loss_fn)
+        # one process: the optimiser step (device-side scaler, lr schedule, EMA decay) is part of the captured step
+        in_graph_opt = world == 1 and scaler is not None
+        graphed = GraphedRenderStep(r, n_rays, loss_fn, optimizer=opt if in_graph_opt else None,
+                                    scaler=scaler if in_graph_opt else None, lr_decay_steps=30000)
 
     # Pixels of a step: n_rays distinct pixels, uniformly at random (np.random.choice(..., replace=False), nerf_lib.py:134).
     # Consecutive chunks of ONE random permutation of the frame are exactly such draws, so a permutation (a device sort: 22
@@ -383,7 +386,9 @@ def run_recon(args, dev, rank, world):
             if graphed is None and it < last_it and not r.occupancy_update_due():
                 pending[it + 1] = r.begin_train(*inputs(it + 1))
             sync.wait()
-        if scaler is not None:
+        if graphed is not None and graphed.optimizer is not None:
+            pass                                               # stepped inside the replayed graph
+        elif scaler is not None:
             opt.step(scaler=scaler, lr_decay_steps=30000)      # lr = 1e-2 * 0.1^(steps / 30000), on the device
         else:
             opt.param_groups[0]['lr'] = exp_lr(1e-2, it, 30000)
@@ -517,7 +522,7 @@ def run_recon(args, dev, rank, world):
     if sp_lambda > 0:
         wl += ', --sparsity_lambda {} (50 000 sigma-only points per step, with gradient)'.format(sp_lambda)
     if args.graph:
-        wl += ', render+loss+backward replayed as one hipGraph'
+        wl += ', render+loss+backward{} replayed as one hipGraph'.format('+optimiser' if graphed.optimizer is not None else '')
     return {
         'metric': 'train Mrays/sec', 'value': round(value, 4), 'unit': 'Mrays/s', 'n_gpus': world, 'steps': args.steps,
         'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True,

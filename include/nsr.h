@@ -317,8 +317,9 @@ int nsr_adam_step(float *params, float *grads, float *exp_avg, float *exp_avg_sq
  * trainers/base.py:228,420-425 and trainers/style.py:200-204, which read the inf flag back to the host every step).
  * scaler_state: device buffer of 16 32-bit words, kept by the caller across steps:
  *   [0] f32 loss scale (initialise to 65536, GradScaler's default)   [1] i32 growth tracker   [2] u32 found_inf
- *   [3] u32 optimiser steps taken   [4] u32 steps skipped   [8..12] this step's values for nsr_adam_step_scaled
- *   (skip flag, lr / (1 - beta1^t), 1 / sqrt(1 - beta2^t), 1 / scale, lr); other words reserved, initialise to 0.
+ *   [3] u32 optimiser steps taken   [4] u32 steps skipped   [5] u32 EMA updates made   [8..13] this step's values for
+ *   nsr_adam_step_scaled (skip flag, lr / (1 - beta1^t), 1 / sqrt(1 - beta2^t), 1 / scale, lr, EMA decay); other words
+ *   reserved, initialise to 0.
  * One optimiser step =
  *   nsr_grad_check        per trained region: sets found_inf if any element selected by elem_mask4 is inf / nan
  *                         (GradScaler.unscale_'s check; untrained regions are not looked at, so data-parallel ranks
@@ -328,6 +329,8 @@ int nsr_adam_step(float *params, float *grads, float *exp_avg, float *exp_avg_sq
  *                         0.1^((t-1) / lr_decay_steps) (LambdaLR advanced only on steps that were not skipped;
  *                         lr_decay_steps <= 0: constant) and Adam's bias corrections for step t, in double precision;
  *                         enabled == 0: never skips, scale stays 1 (GradScaler(enabled=False)); clears found_inf;
+ *                         ema_decay_max >= 0: torch_ema's schedule, num_updates += 1 and decay = min(ema_decay_max,
+ *                         (1 + n) / (10 + n)) on every call (skipped steps included); < 0: no EMA;
  *   nsr_adam_step_scaled  per trained region: nsr_adam_step with those device-side scalars; on a skipped step the
  *                         parameters and moments stay, the gradient is still zeroed and the EMA still moves
  *                         (ema.update() is unconditional, base.py:426).  half_copy covers the first half_n elements.
@@ -335,10 +338,10 @@ int nsr_adam_step(float *params, float *grads, float *exp_avg, float *exp_avg_sq
 int nsr_grad_check(const float *grads, uint64_t n, uint32_t elem_mask4, void *scaler_state, nsr_stream_t stream);
 int nsr_scaler_update(void *scaler_state, float lr_base, float lr_decay_steps, float beta1, float beta2,
                       float growth_factor, float backoff_factor, uint32_t growth_interval, int enabled,
-                      nsr_stream_t stream);
+                      float ema_decay_max, nsr_stream_t stream);
 int nsr_adam_step_scaled(float *params, float *grads, float *exp_avg, float *exp_avg_sq, float *ema,
                          void *half_copy, uint64_t n, uint64_t half_n, float beta1, float beta2, float eps,
-                         float ema_decay, uint32_t elem_mask4, const void *scaler_state, nsr_stream_t stream);
+                         uint32_t elem_mask4, const void *scaler_state, nsr_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Occupancy-grid update on the device: replaces Renderer.update_state / _compute_occ_sigmas

@@ -75,8 +75,8 @@ SIGNATURES = {
     'nsr_cast_f32_to_f16': (i32, [vp, vp, u64, vp]),
     'nsr_adam_step': (i32, [vp, vp, vp, vp, vp, vp, u64, f32, f32, f32, f32, f32, f32, u32, u32, vp]),
     'nsr_grad_check': (i32, [vp, u64, u32, vp, vp]),
-    'nsr_scaler_update': (i32, [vp, f32, f32, f32, f32, f32, f32, u32, i32, vp]),
-    'nsr_adam_step_scaled': (i32, [vp, vp, vp, vp, vp, vp, u64, u64, f32, f32, f32, f32, u32, vp, vp]),
+    'nsr_scaler_update': (i32, [vp, f32, f32, f32, f32, f32, f32, u32, i32, f32, vp]),
+    'nsr_adam_step_scaled': (i32, [vp, vp, vp, vp, vp, vp, u64, u64, f32, f32, f32, u32, vp, vp]),
     'nsr_occ_workspace_bytes': (u64, [u32, u32]),
     'nsr_occ_num_points': (u32, [u32, u32, i32]),
     'nsr_occ_sample_points': (i32, [vp, u32, u32, f32, i32, u64, u32, vp, vp, vp, vp, vp, vp]),

@@ -16,11 +16,11 @@ struct AdamArgs {
 // Device-side GradScaler + step bookkeeping (torch.cuda.amp.GradScaler's policy, trainers/base.py:228,420-425), 16 words:
 //   [0] f32 scale   [1] i32 growth tracker   [2] u32 found_inf (set by k_grad_check, consumed by k_scaler_update)
 //   [3] u32 optimiser steps taken (skipped steps do not count: bias corrections and the LambdaLR schedule follow it)
-//   [4] u32 steps skipped so far   [5..7] reserved
+//   [4] u32 steps skipped so far   [5] u32 EMA updates made (torch_ema's num_updates)   [6..7] reserved
 //   [8] u32 skip this step   [9] f32 step_size = lr / (1 - beta1^t)   [10] f32 1 / sqrt(1 - beta2^t)
-//   [11] f32 1 / scale (the scale the gradients carry)   [12] f32 lr   [13..15] reserved
-enum { SC_SCALE = 0, SC_TRACKER = 1, SC_FOUND = 2, SC_STEP = 3, SC_SKIPPED = 4, SC_SKIP = 8, SC_STEP_SIZE = 9, SC_INV_BC2 = 10,
-       SC_INV_SCALE = 11, SC_LR = 12 };
+//   [11] f32 1 / scale (the scale the gradients carry)   [12] f32 lr   [13] f32 EMA decay of this step   [14..15] reserved
+enum { SC_SCALE = 0, SC_TRACKER = 1, SC_FOUND = 2, SC_STEP = 3, SC_SKIPPED = 4, SC_EMA_N = 5, SC_SKIP = 8, SC_STEP_SIZE = 9,
+       SC_INV_BC2 = 10, SC_INV_SCALE = 11, SC_LR = 12, SC_EMA_DECAY = 13 };
 
 __device__ __forceinline__ float adam_one(float &p, float g, float &m, float &v, const AdamArgs &a) {
     g *= a.grad_scale_inv;
@@ -61,8 +61,15 @@ k_grad_check(const float *__restrict__ g, uint64_t n, uint32_t mask4, uint32_t *
 // one thread: GradScaler.step's decision + GradScaler.update + the step counter, the LambdaLR value and Adam's bias
 // corrections (double precision, as torch computes them on the host)
 __global__ void k_scaler_update(uint32_t *st, float lr_base, float lr_decay_steps, float beta1, float beta2, float growth,
-                                float backoff, uint32_t growth_interval, int enabled) {
+                                float backoff, uint32_t growth_interval, int enabled, float ema_decay_max) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (ema_decay_max >= 0.0f) {
+        // torch_ema (utils/__init__.py:116-142): num_updates += 1; decay = min(decay, (1 + n) / (10 + n)) -- on every call,
+        // skipped optimiser steps included (ema.update() is unconditional, trainers/base.py:426)
+        const uint32_t n = st[SC_EMA_N] + 1u;
+        st[SC_EMA_N] = n;
+        st[SC_EMA_DECAY] = __float_as_uint(fminf(ema_decay_max, (1.0f + (float)n) / (10.0f + (float)n)));
+    }
     float scale = __uint_as_float(st[SC_SCALE]);
     const bool inf = enabled && st[SC_FOUND] != 0u;
     st[SC_FOUND] = 0u;
@@ -102,6 +109,7 @@ k_adam(AdamArgs a) {
         a.step_size = __uint_as_float(a.dyn[SC_STEP_SIZE]);
         a.inv_sqrt_bc2 = __uint_as_float(a.dyn[SC_INV_BC2]);
         a.grad_scale_inv = __uint_as_float(a.dyn[SC_INV_SCALE]);
+        if (a.ema) a.ema_decay = __uint_as_float(a.dyn[SC_EMA_DECAY]);
     }
     if (skip) {
         // GradScaler skipped optimizer.step(): parameters and moments stay; the gradient is cleared (the reference's
@@ -197,17 +205,18 @@ extern "C" int nsr_grad_check(const float *grads, uint64_t n, uint32_t elem_mask
 }
 
 extern "C" int nsr_scaler_update(void *scaler_state, float lr_base, float lr_decay_steps, float beta1, float beta2, float growth_factor,
-                                 float backoff_factor, uint32_t growth_interval, int enabled, nsr_stream_t stream) {
+                                 float backoff_factor, uint32_t growth_interval, int enabled, float ema_decay_max,
+                                 nsr_stream_t stream) {
     NSR_CHECK_PTR(scaler_state);
     if (((uintptr_t)scaler_state & 3u) || growth_interval == 0) return NSR_ERR_INVALID_ARG;
     hipLaunchKernelGGL(k_scaler_update, dim3(1), dim3(64), 0, (hipStream_t)stream, (uint32_t *)scaler_state, lr_base, lr_decay_steps, beta1,
-                       beta2, growth_factor, backoff_factor, growth_interval, enabled);
+                       beta2, growth_factor, backoff_factor, growth_interval, enabled, ema_decay_max);
     return nsr_launch_status();
 }
 
 extern "C" int nsr_adam_step_scaled(float *params, float *grads, float *exp_avg, float *exp_avg_sq, float *ema, void *half_copy,
-                                    uint64_t n, uint64_t half_n, float beta1, float beta2, float eps, float ema_decay,
-                                    uint32_t elem_mask4, const void *scaler_state, nsr_stream_t stream) {
+                                    uint64_t n, uint64_t half_n, float beta1, float beta2, float eps, uint32_t elem_mask4,
+                                    const void *scaler_state, nsr_stream_t stream) {
     if (n == 0) return NSR_OK;
     NSR_CHECK_PTR(params); NSR_CHECK_PTR(grads); NSR_CHECK_PTR(exp_avg); NSR_CHECK_PTR(exp_avg_sq); NSR_CHECK_PTR(scaler_state);
     const uintptr_t al = (uintptr_t)params | (uintptr_t)grads | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq |
@@ -217,7 +226,7 @@ extern "C" int nsr_adam_step_scaled(float *params, float *grads, float *exp_avg,
     a.p = params; a.g = grads; a.m = exp_avg; a.v = exp_avg_sq; a.ema = ema; a.half_copy = (_Float16 *)half_copy; a.n = n;
     a.half_n = half_n; a.dyn = (const uint32_t *)scaler_state;
     a.mask4 = elem_mask4 & 0xFu;
-    a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.ema_decay = ema_decay;
+    a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.ema_decay = 0.0f;           // (read from the state in the kernel)
     a.step_size = 0.0f; a.inv_sqrt_bc2 = 1.0f; a.grad_scale_inv = 1.0f;
     return adam_launch(a, (hipStream_t)stream);
 }

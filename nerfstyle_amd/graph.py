@@ -23,7 +23,13 @@ class GraphedRenderStep:
     Gradients accumulate into model.arena.grad exactly as in eager mode."""
 
     def __init__(self, renderer: Renderer, n_rays: int, loss_fn: Callable[[Dict[str, torch.Tensor], torch.Tensor], torch.Tensor],
-                 warmup: int = 2, dense: bool = False):
+                 warmup: int = 2, dense: bool = False, optimizer=None, scaler=None, lr_decay_steps: float = 0.0):
+        # optimizer (FusedAdam) + scaler (LossScaler): the optimiser step joins the graph.  Possible since round 3: learning rate,
+        # step count, bias corrections, loss scale, skip decision and the EMA decay are device-side scalars (nsr_scaler_update),
+        # so nothing the captured kernels need changes on the host from step to step.  Without them the caller steps the
+        # optimiser after the replay (e.g. data-parallel runs: the gradient all-reduce sits between backward and optimiser).
+        assert (optimizer is None) == (scaler is None), 'a captured optimiser step needs the device-side LossScaler'
+        self.optimizer, self.scaler, self.lr_decay_steps = optimizer, scaler, lr_decay_steps
         # dense: the pixel sets are patches / crops / whole frames (neighbouring pixels): Renderer._use_spatial_order then picks
         # the spatial sample order + lattice scatter from 16 384 rays on, inside the graph like everything else
         self.dense = dense
@@ -41,7 +47,7 @@ class GraphedRenderStep:
         self.loss = None
         self._warmup = warmup
 
-    def _body(self):
+    def _body(self, with_optimizer=True):
         keep = self.r.update_occ
         self.r.update_occ = False          # inside the graph: fixed launch sequence, a private device-side counter
         try:
@@ -50,6 +56,8 @@ class GraphedRenderStep:
             self.r.update_occ = keep
         loss = self.loss_fn(out, self.pix)
         loss.backward()
+        if with_optimizer and self.optimizer is not None:
+            self.optimizer.step(scaler=self.scaler, lr_decay_steps=self.lr_decay_steps)
         return loss.detach()
 
     def capture(self, pose: torch.Tensor, pix: torch.Tensor):
@@ -64,9 +72,15 @@ class GraphedRenderStep:
         # warm-up on a side stream (allocator pools, lazy initialisation), as torch.cuda.graphs asks
         s = torch.cuda.Stream(device=self.r.device)
         s.wait_stream(torch.cuda.current_stream())
+        if self.optimizer is not None:
+            # the scaler state lives on the device before capture (no allocation / upload inside it), and the EMA count moves there
+            self.scaler.state_on(self.r.device)
+            if getattr(self.optimizer, '_scaler', None) is not self.scaler:
+                self.scaler.adopt_ema_updates(self.optimizer.ema_updates, self.r.device)
+                self.optimizer._scaler = self.scaler
         with torch.cuda.stream(s):
             for _ in range(self._warmup):
-                self._body()
+                self._body(with_optimizer=False)   # warm-up renders only: no parameter update, no step counted
         torch.cuda.current_stream().wait_stream(s)
         model.arena.grad.zero_()           # the warm-up passes accumulated gradients
         self.graph = torch.cuda.CUDAGraph()

@@ -91,11 +91,11 @@ class FusedAdam:
         g = m._ensure_grad()
         a = m.arena.detach()
         half = m.half_tables() if m.table_dtype == torch.float16 else None
-        decay = self._ema_decay_now()
         ptr = lambda t, off: t.data_ptr() + off * 4
         regions = self._regions()
         if scaler is None:
             self.step_count += 1
+            decay = self._ema_decay_now()
             lr = self.param_groups[0]['lr']
             for (off, n, mask, half_n) in regions:
                 # the host-scalar entry point has no half_n: a whole-arena region is split at the table end
@@ -108,21 +108,24 @@ class FusedAdam:
                         float(self.betas[1]), float(self.eps), float(1.0 / grad_scale), float(decay), self.step_count, mask,
                         L.stream()), 'adam_step')
         else:
+            if getattr(self, '_scaler', None) is not scaler:
+                # first step with this scaler: the EMA update count moves to the device (torch_ema's decay schedule follows it)
+                scaler.adopt_ema_updates(self.ema_updates, a.device)
+                self._scaler = scaler
             st = scaler.state_on(a.device)
             for (off, n, mask, half_n) in regions:
                 L.check(L.lib().nsr_grad_check(ptr(g, off), n, mask, L.p(st), L.stream()), 'grad_check')
             L.check(L.lib().nsr_scaler_update(L.p(st), float(self.param_groups[0]['initial_lr']), float(lr_decay_steps),
                                               float(self.betas[0]), float(self.betas[1]), float(scaler.growth_factor),
                                               float(scaler.backoff_factor), int(scaler.growth_interval), int(scaler.enabled),
-                                              L.stream()), 'scaler_update')
+                                              float(self.ema_decay) if self.ema is not None else -1.0, L.stream()), 'scaler_update')
             for (off, n, mask, half_n) in regions:
                 L.check(L.lib().nsr_adam_step_scaled(
                     ptr(a, off), ptr(g, off), ptr(self.exp_avg, off), ptr(self.exp_avg_sq, off),
                     ptr(self.ema, off) if self.ema is not None else None,
                     half.data_ptr() if (half is not None and off == 0 and half_n) else None, n, half_n if half is not None else 0,
-                    float(self.betas[0]), float(self.betas[1]), float(self.eps), float(decay), mask, L.p(st), L.stream()),
+                    float(self.betas[0]), float(self.betas[1]), float(self.eps), mask, L.p(st), L.stream()),
                     'adam_step_scaled')
-            self._scaler = scaler
         self._zero_untrained(g)
         if half is not None and self.table_mask:
             m.mark_half_synced()
@@ -133,9 +136,14 @@ class FusedAdam:
         sc = getattr(self, '_scaler', None)
         return int(sc.state[3].item()) if sc is not None and sc.state is not None else self.step_count
 
+    @property
+    def ema_updates_made(self):
+        sc = getattr(self, '_scaler', None)
+        return int(sc.state[5].item()) if sc is not None and sc.state is not None else self.ema_updates
+
     def state_dict(self):
         return {'step': self.steps_taken, 'exp_avg': self.exp_avg, 'exp_avg_sq': self.exp_avg_sq, 'ema': self.ema,
-                'ema_updates': self.ema_updates, 'lr': self.param_groups[0]['lr']}
+                'ema_updates': self.ema_updates_made, 'lr': self.param_groups[0]['lr']}
 
     def load_reference_state(self, optim_sd, ema_sd=None):
         """State of the REFERENCE's optimiser objects: torch.optim.Adam.state_dict() ({'state': {i: {'step', 'exp_avg',
@@ -211,7 +219,7 @@ class LossScaler:
         self.enabled = enabled
         self.state = None
         # host-side values, uploaded when the device is known (and the source of state_dict() until then)
-        self._pending = {'scale': self.init_scale, '_growth_tracker': 0, 'steps': 0, 'skipped': 0}
+        self._pending = {'scale': self.init_scale, '_growth_tracker': 0, 'steps': 0, 'skipped': 0, 'ema_updates': 0}
 
     def state_on(self, device):
         if self.state is None or self.state.device != device:
@@ -219,13 +227,23 @@ class LossScaler:
             vals = self._pending if self._pending is not None else self._read_back()
             host[0:1].view(torch.float32)[0] = float(vals['scale'])
             host[1], host[3], host[4] = int(vals['_growth_tracker']), int(vals['steps']), int(vals['skipped'])
+            host[5] = int(vals.get('ema_updates', 0))
             self.state = host.to(device)
             self._pending = None
         return self.state
 
     def _read_back(self):
         st = self.state.cpu()
-        return {'scale': float(st[0:1].view(torch.float32)[0]), '_growth_tracker': int(st[1]), 'steps': int(st[3]), 'skipped': int(st[4])}
+        return {'scale': float(st[0:1].view(torch.float32)[0]), '_growth_tracker': int(st[1]), 'steps': int(st[3]), 'skipped': int(st[4]),
+                'ema_updates': int(st[5])}
+
+    def adopt_ema_updates(self, n, device):
+        """The optimiser's host-side EMA update count becomes the device-side one (first scaled step / after a restore)."""
+        if self.state is None:
+            self._pending['ema_updates'] = max(int(n), int(self._pending.get('ema_updates', 0)))
+            self.state_on(device)
+        else:
+            self.state[5:6].clamp_(min=int(n))                  # device op: no host read
 
     def scale_tensor(self, device):
         """0-dim float32 view of the device-side scale (what `scale(loss)` multiplies by)."""
@@ -251,7 +269,8 @@ class LossScaler:
         self.growth_factor, self.backoff_factor = sd['growth_factor'], sd['backoff_factor']
         self.growth_interval = sd['growth_interval']
         self._pending = {'scale': float(sd['scale']), '_growth_tracker': int(sd.get('_growth_tracker', 0)),
-                         'steps': int(sd.get('steps', 0)), 'skipped': int(sd.get('skipped', 0))}
+                         'steps': int(sd.get('steps', 0)), 'skipped': int(sd.get('skipped', 0)),
+                         'ema_updates': int(sd.get('ema_updates', 0))}
         dev = self.state.device if self.state is not None else None
         self.state = None
         if dev is not None:

@@ -587,7 +587,7 @@ def test_checkpoint_roundtrip_on_the_gpu_is_bit_identical(O, dev, tmp_path):
     assert torch.equal(a['rgb_map'], b['rgb_map']) and torch.equal(a['classes'], b['classes'])
     assert torch.equal(r.density_bitfield, r2.density_bitfield) and r2.local_step == r.local_step == 5
     assert torch.equal(m.arena.detach(), m2.arena.detach()) and torch.equal(opt.exp_avg, opt2.exp_avg)
-    assert torch.equal(opt.exp_avg_sq, opt2.exp_avg_sq) and torch.equal(opt.ema, opt2.ema) and opt2.ema_updates == opt.ema_updates
+    assert torch.equal(opt.exp_avg_sq, opt2.exp_avg_sq) and torch.equal(opt.ema, opt2.ema) and opt2.ema_updates == opt.ema_updates_made == 5
     train_step(m, r, opt, sc, pixs[5])
     train_step(m2, r2, opt2, sc2, pixs[5])
     # the table gradient is summed by float atomics in arrival order: a step is reproducible to fp32 rounding, not bit for bit
@@ -851,6 +851,72 @@ def test_bf16_graph_replayed_training_step(O, dev):
         opt.step()
     assert r.local_step == 18 and int(r._occ_state[0]) == 2 and np.all(np.isfinite(losses))
     assert int(r.density_bitfield.count_nonzero()) > 0
+
+
+def test_graph_with_optimiser_inside_equals_eager_steps(O, dev):
+    """GraphedRenderStep(optimizer=..., scaler=...): the optimiser step -- inf/nan check, GradScaler policy, LambdaLR value, Adam
+    bias corrections and torch_ema's decay schedule, all device-side scalars -- is part of the replayed graph.  Five replayed
+    steps on a dense 160 x 128 patch (spatial sample order + lattice scatter inside the graph, f16 tables and MFMA, loss scale
+    with growth_interval 2 so the scale changes between replays, one step with an inf in the gradient path via an inf target)
+    leave the same parameters, EMA shadow, scale and step counts as the same five steps run eagerly."""
+    from nerfstyle_amd.common import BBox
+    from nerfstyle_amd.config import NetworkConfig, RendererConfig
+    from nerfstyle_amd.graph import GraphedRenderStep
+    from nerfstyle_amd.optim import FusedAdam, LossScaler
+    from nerfstyle_amd.recon_loss import recon_loss
+    from nerfstyle_amd.renderer import Renderer
+    from nerfstyle_amd.scene import load_room_cameras
+    from nerfstyle_amd.style_nerf import StyleTCNerf
+    poses, intr, _ = load_room_cameras()
+    nc = 5
+    W = intr.w
+    rows, cols = torch.arange(100, 228, device=dev), torch.arange(50, 210, device=dev)
+    pix = (rows[:, None] * W + cols[None, :]).reshape(-1)                  # 20 480 dense pixels
+    g = torch.Generator(device=dev)
+    g.manual_seed(12)
+    t_rgb = torch.rand(intr.w * intr.h, 3, device=dev, generator=g)
+    t_cls = torch.randint(0, nc, (intr.w * intr.h,), device=dev, generator=g)
+    pose_t = torch.tensor(poses, device=dev)
+    grid, bits = small_scene()
+
+    def build():
+        m = StyleTCNerf(NetworkConfig(), BBox.from_radius(2.0), nc, enc_dtype=None, use_dir=False)
+        with torch.no_grad():
+            m.arena[:m.table_elems].uniform_(-0.3, 0.3, generator=torch.Generator().manual_seed(1))
+            m.arena.add_(0)
+        r = Renderer(m, RendererConfig.llff(), intr, 2.0, raymarch_channels=3 + nc, samples_per_ray_cap=192).to(dev)
+        r.density_grid = torch.tensor(grid, device=dev)
+        r.density_bitfield = torch.tensor(bits, device=dev)
+        r.update_occ = False
+        return m, r, FusedAdam(m, lr=1e-2, ema_decay=0.95), LossScaler(init_scale=256.0, growth_interval=2)
+    targets = [t_rgb, t_rgb, t_rgb.clone(), t_rgb, t_rgb]
+    targets[2][pix[::5]] = float('inf')                                     # step 2: inf loss gradients on every 5th ray (about a
+                                                                            # third of the rays carry samples) -> skipped, back-off
+    cur = {'t': t_rgb.clone()}
+
+    def run(graphed):
+        m, r, opt, sc = build()
+        assert r._use_spatial_order(pix.numel(), True)
+
+        def loss_fn(o, p):
+            return recon_loss(o['rgb_map'], o['classes'], cur['t'], t_cls, p, scale=sc.scale_tensor(dev))
+        step = GraphedRenderStep(r, pix.numel(), loss_fn, dense=True, optimizer=opt, scaler=sc, lr_decay_steps=50.0) if graphed else None
+        for it in range(5):
+            cur['t'].copy_(targets[it])                                    # a static buffer: replays read the new contents
+            if graphed:
+                step(pose_t[it], pix)
+            else:
+                out = r.render(pose_t[it], None, training=True, pix_subset=pix, dense=True)
+                loss_fn(out, pix).backward()
+                opt.step(scaler=sc, lr_decay_steps=50.0)
+        return m.arena.detach().clone(), opt.ema.clone(), sc.state_dict(), opt.steps_taken, opt.ema_updates_made
+    a_e, ema_e, sc_e, steps_e, n_e = run(False)
+    a_g, ema_g, sc_g, steps_g, n_g = run(True)
+    assert sc_e == sc_g and sc_e['skipped'] == 1 and steps_e == steps_g == 4 and n_e == n_g == 5
+    assert sc_e['scale'] == 256.0 * 2 * 0.5 * 2                             # grew after 2 clean steps, backed off, grew again
+    d = (a_g - a_e).abs()
+    assert float((d > 1e-5).float().mean()) < 2e-3                          # fp32 atomics order: a few near-zero gradients flip sign
+    assert float((ema_g - ema_e).abs().max()) < 0.05 and float((ema_g - a_g).abs().max()) > 1e-4
 
 
 def test_graphed_patch_backward_equals_eager(O, dev):
