@@ -387,7 +387,25 @@ k_march_wpr(const float *__restrict__ rays_o, const float *__restrict__ rays_d, 
     while (!done && t_block < far) {
         // ---- the block's 64 parameters: every lane runs the serial recurrence and keeps its own ----
         float my_t = t_block, tc = t_block;
-        {
+        bool closed = false;
+        if (dt_gamma == 0.0f && t_block > 0.0f) {
+            // Constant step (LLFF: dt_gamma = 0): t_{j+1} = fl(t_j + dt).  Inside one binade every t_j is a multiple of the
+            // binade's ulp u, so the rounded sum advances the BIT PATTERN by a constant c = dt / u rounded to an integer (ties
+            // to even make the very first step the only possible exception: after it the mantissa parity repeats).  Two real
+            // additions give t_1 and t_2, c = bits(t_2) - bits(t_1), and t_j = bits(t_1) + (j - 1) c for j = 1..64 -- the same
+            // floats as the 64 serial additions below, as long as t_1 .. t_64 share an exponent (else: the serial loop).
+#pragma clang fp contract(off)
+            const float dt0 = rm_clamp(t_block * dt_gamma, c.dt_min, c.dt_max);
+            const float t1 = t_block + dt0, t2 = t1 + dt0;
+            const uint32_t b1 = __float_as_uint(t1), b2 = __float_as_uint(t2), cc = b2 - b1;
+            const uint32_t b64 = b1 + 63u * cc;
+            if (b2 > b1 && (b1 >> 23) == (b64 >> 23) && cc < (1u << 23)) {
+                closed = true;
+                my_t = lane == 0 ? t_block : __uint_as_float(b1 + (lane - 1u) * cc);
+                tc = __uint_as_float(b64);
+            }
+        }
+        if (!closed) {
 #pragma clang fp contract(off)
             for (uint32_t j = 0; j < 64; j++) {
                 if (lane == j) my_t = tc;
