@@ -1126,18 +1126,49 @@ k_field_bwd(FieldBwdArgs b) {
         scq_pace(q, gt1, lane, td, tc, 1 << 20, true);
     }
 
-    // ---- flush this wave's weight gradients -------------------------------------------------------
+    // ---- weight gradients: summed over the workgroup's waves in LDS, then ONE wave adds them to grad_mlp ----------------
+    // Every wave holds 60 tiles = 15 360 partial sums.  Flushed wave by wave (rounds 1-2) that is 240 atomic wave-instructions
+    // x 4 64-byte requests from each of 1 024 waves onto the same 960 lines -- ~1 M requests at the hot-line rate of the
+    // memory-side atomic unit (5.5 G/s, tools/atomic_footprint_bench.hip): 0.18 ms per launch whatever the batch, half of a
+    // 4 096-ray step's backward.  The weight-fragment image (61 440 B = exactly 60 tiles x 64 lanes x 16 B) is dead by now and
+    // serves as the reduction buffer: four passes of read-add-write, then wave 0 reloads the totals and flushes them --
+    // a quarter of the requests, and fp32 sums of four partials instead of four atomics (same value up to rounding order).
     if (b.grad_mlp) {
-        float *gm = b.grad_mlp;
-        field_wgrad_flush<1, 4>(gm + P_R3, 64, 0, 3, w_r3, lane);
-        field_wgrad_flush<4, 4>(gm + P_R2, 64, 0, 64, w_r2, lane);
-        field_wgrad_flush<4, 1>(gm + P_R1, 16, 0, 64, w_r1, lane);
-        field_wgrad_flush<1, 4>(gm + P_C1B, 64, 0, 16, w_c1b, lane);
-        field_wgrad_flush<4, 2>(gm + P_C1A, 32, 0, 64, w_c1a, lane);
-        field_wgrad_flush<1, 4>(gm + P_K2, 64, CLASS_ROW_SHIFT, nc, w_k2, lane);
-        field_wgrad_flush<4, 2>(gm + P_K1, 32, 0, 64, w_k1, lane);
-        field_wgrad_flush<1, 4>(gm + P_D2, 64, 0, 1, w_d2, lane);
-        field_wgrad_flush<4, 2>(gm + P_D1, 32, 0, 64, w_d1, lane);
+        f4v *const red = reinterpret_cast<f4v *>(smem);
+#define NSR_RED_ALL(OP)                                                                                              \
+        OP(w_r3, 0, 4) OP(w_r2, 4, 16) OP(w_r1, 20, 4) OP(w_c1b, 24, 4) OP(w_c1a, 28, 8) OP(w_k2, 36, 4) OP(w_k1, 40, 8)     \
+        OP(w_d2, 48, 4) OP(w_d1, 52, 8)
+        __syncthreads();                                   // every wave is done with the weight fragments
+        for (int w = 0; w < BWD_THREADS / 64; w++) {
+            if (wave == w) {
+                if (w == 0) {
+#define NSR_RED_ST(arr, base, n) _Pragma("unroll") for (int i = 0; i < n; i++) red[((base) + i) * 64 + lane] = arr[i];
+                    NSR_RED_ALL(NSR_RED_ST)
+#undef NSR_RED_ST
+                } else {
+#define NSR_RED_ADD(arr, base, n) _Pragma("unroll") for (int i = 0; i < n; i++) red[((base) + i) * 64 + lane] += arr[i];
+                    NSR_RED_ALL(NSR_RED_ADD)
+#undef NSR_RED_ADD
+                }
+            }
+            __syncthreads();
+        }
+        if (wave == 0) {
+#define NSR_RED_LD(arr, base, n) _Pragma("unroll") for (int i = 0; i < n; i++) arr[i] = red[((base) + i) * 64 + lane];
+            NSR_RED_ALL(NSR_RED_LD)
+#undef NSR_RED_LD
+            float *gm = b.grad_mlp;
+            field_wgrad_flush<1, 4>(gm + P_R3, 64, 0, 3, w_r3, lane);
+            field_wgrad_flush<4, 4>(gm + P_R2, 64, 0, 64, w_r2, lane);
+            field_wgrad_flush<4, 1>(gm + P_R1, 16, 0, 64, w_r1, lane);
+            field_wgrad_flush<1, 4>(gm + P_C1B, 64, 0, 16, w_c1b, lane);
+            field_wgrad_flush<4, 2>(gm + P_C1A, 32, 0, 64, w_c1a, lane);
+            field_wgrad_flush<1, 4>(gm + P_K2, 64, CLASS_ROW_SHIFT, nc, w_k2, lane);
+            field_wgrad_flush<4, 2>(gm + P_K1, 32, 0, 64, w_k1, lane);
+            field_wgrad_flush<1, 4>(gm + P_D2, 64, 0, 1, w_d2, lane);
+            field_wgrad_flush<4, 2>(gm + P_D1, 32, 0, 64, w_d1, lane);
+        }
+#undef NSR_RED_ALL
     }
 }
 

@@ -236,6 +236,15 @@ k_table_scatter(TableScatterArgs a) {
     LatState st;
     st.b0 = st.b1 = st.b2 = LAT_NONE;
     uint32_t cur_key = LAT_NONE;
+    // Round 3: the per-step index arithmetic runs in fp32 (cells, anchors and lattice coordinates are integers < 2^24: exact),
+    // which saves the three float->int conversions, the 24-bit integer multiplies and a quarter-rate 64-bit multiply-add of
+    // the slot address; the corner weights of the lane's fixed (y, z) corner are one FMA each (w = f * s + o with (s, o) =
+    // (1, 0) or (-1, 1)).  The kernel is instruction-issue bound: ~300 issue cycles per step per wave, 168 of them VALU.
+    float bf0 = 0.f, bf1 = 0.f, bf2 = 0.f;                           // the anchor (st.b*) as floats
+    const float lscale = (float)lv.resolution;                        // nsr_grid_locate with align_corners = 1
+    const float lcmax = (float)(lv.resolution - 1u);
+    const float Sf = (float)S, Sm2 = (float)(S - 2u);
+    const float sy = py ? 1.0f : -1.0f, oy = py ? 0.0f : 1.0f, sz = pz ? 1.0f : -1.0f, oz = pz ? 0.0f : 1.0f;
 
     // position 16 * tile + s of the order -> buffer index; lanes past the count read the last valid entry (masked later)
     auto fetch_idx = [&](uint32_t tile) -> uint32_t { return a.perm[min(tile * 16 + (uint32_t)s, Mc - 1u)]; };
@@ -267,6 +276,13 @@ k_table_scatter(TableScatterArgs a) {
         const uint32_t q0 = (uint32_t)fminf(fmaxf(u0 * kq, 0.0f), kq - 1.0f), q1 = (uint32_t)fminf(fmaxf(u1 * kq, 0.0f), kq - 1.0f),
                        q2 = (uint32_t)fminf(fmaxf(u2 * kq, 0.0f), kq - 1.0f);
         const uint32_t bkey = q0 | (q1 << LAT_KEY_BITS) | (q2 << (2 * LAT_KEY_BITS));
+        // steps at which the block key MAY differ from the previous live sample's: this sample's key against its left
+        // neighbour's (lane 0: against the key the walk is in; dead samples carry a sentinel, so the live sample after one is
+        // always flagged).  The exact test runs inside the flagged steps only -- one scalar bit test per step instead of a
+        // cross-lane read and a compare.
+        const uint32_t bkey_e = live ? bkey : LAT_NONE;
+        const uint32_t bkey_l = (uint32_t)__builtin_amdgcn_update_dpp((int)cur_key, (int)bkey_e, 0x111, 0xF, 0xF, false);   // row_shr:1
+        const uint32_t chg16 = (uint32_t)(__ballot(bkey_e != bkey_l) & 0xFFFFull);
 #if NSR_TS_RING
 #pragma unroll 1
         for (int part = 0; part < 16 / NSR_TS_RING; part++) {
@@ -289,7 +305,8 @@ k_table_scatter(TableScatterArgs a) {
             if (step < 15) gr_next = TS_GIN(idx, step + 1);
             if (!((live16 >> step) & 1u)) continue;                            // wave-uniform
 #endif
-            const uint32_t key = (uint32_t)__builtin_amdgcn_readlane((int)bkey, step);
+            uint32_t key = cur_key;
+            if ((chg16 >> step) & 1u) key = (uint32_t)__builtin_amdgcn_readlane((int)bkey, step);       // wave-uniform
             if (key != cur_key) {
                 // ---- the walk enters another block: re-anchor every level at the cell of the block's origin ----
                 cur_key = key;
@@ -310,24 +327,28 @@ k_table_scatter(TableScatterArgs a) {
                     mm &= ~(0xFull << (fl * 4));
                     lat_flush_dispatch(lat, fl, st, lds_lv, gt, lane, td, tc);
                 }
-                if (chg) { st.b0 = n0; st.b1 = n1; st.b2 = n2; }
+                if (chg) { st.b0 = n0; st.b1 = n1; st.b2 = n2; bf0 = (float)n0; bf1 = (float)n1; bf2 = (float)n2; }
             }
             const float su0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, u0), step));
             const float su1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, u1), step));
             const float su2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, u2), step));
-            float f0, f1, f2;
-            uint32_t c0, c1, c2;
-            nsr_grid_locate(su0, lv.resolution, 1, f0, c0);
-            nsr_grid_locate(su1, lv.resolution, 1, f1, c1);
-            nsr_grid_locate(su2, lv.resolution, 1, f2, c2);
+            // nsr_grid_locate (align_corners = 1) with the cell kept as a float: p = u * res, c = min(floor(p), res - 1), f = p - c
+            float f0, f1, f2, cf0, cf1, cf2;
+            {
+#pragma clang fp contract(off)
+                const float p0 = su0 * lscale, p1 = su1 * lscale, p2 = su2 * lscale;
+                cf0 = fminf(floorf(p0), lcmax); cf1 = fminf(floorf(p1), lcmax); cf2 = fminf(floorf(p2), lcmax);
+                f0 = p0 - cf0; f1 = p1 - cf1; f2 = p2 - cf2;
+            }
             // cell relative to the anchor: 0 .. S - 2 by construction (the sample lies in the block the anchor was taken
             // from; floor(u * res) is monotonic in u)
-            const uint32_t d0 = c0 - st.b0, d1 = c1 - st.b1, d2 = c2 - st.b2;
-            const uint32_t r0 = min(d0, S - 2u), r1 = min(d1, S - 2u), r2 = min(d2, S - 2u);
-            // this sample's contribution to the lane's two x corners: (wx*wy)*wz, the product order of the forward
-            const float wy = py ? f1 : 1 - f1, wz = pz ? f2 : 1 - f2;
-            float wA = ((1 - f0) * wy) * wz, wB = (f0 * wy) * wz;
-            if (max(d0, max(d1, d2)) > S - 2u) {
+            const float d0 = cf0 - bf0, d1 = cf1 - bf1, d2 = cf2 - bf2;
+            const float r0 = fminf(d0, Sm2), r1 = fminf(d1, Sm2), r2 = fminf(d2, Sm2);
+            // this sample's contribution to the lane's two x corners
+            const float wyz = fmaf(f1, sy, oy) * fmaf(f2, sz, oz);
+            float wB = f0 * wyz, wA = wyz - wB;
+            if (fmaxf(d0, fmaxf(d1, d2)) > Sm2) {
+                const uint32_t c0 = (uint32_t)cf0, c1 = (uint32_t)cf1, c2 = (uint32_t)cf2;
                 // fp32 rounding put the cell one past the lattice (u * res of a sample at the very end of its block can
                 // round up across a cell boundary that the block's real extent stops short of): this sample's two corners
                 // go straight to the table, exactly; the (clamped) lattice slots get nothing
@@ -344,7 +365,7 @@ k_table_scatter(TableScatterArgs a) {
                 wA = 0.0f;
                 wB = 0.0f;
             }
-            float4 *const slot = mylat + (__umul24(__umul24(r2, S) + r1, S) + r0);
+            float4 *const slot = mylat + (uint32_t)fmaf(fmaf(r2, Sf, r1), Sf, r0);
 #if NSR_TS_LDS_ATOMIC
             // fire-and-forget LDS float adds: no read -> fma -> write round trip to wait for (the lattice is private to the wave
             // and the 64 lanes of a step touch 128 different slots, so nothing conflicts)
