@@ -46,8 +46,9 @@ def main(root, tag, samples_per_launch):
         'kernels': {},
     }
     for k in sorted(set(fetch) | set(write)):
-        short = next((n for n in ('k_field_bwd', 'k_field_fwd', 'k_table_scatter', 'k_order_keys', 'k_composite_train_fwd', 'k_composite_train_bwd',
-                                  'k_march_count', 'k_march_emit', 'k_adam') if n in k), None)
+        short = next((n for n in ('k_field_bwd', 'k_field_fwd', 'k_table_scatter', 'k_order_keys', 'k_sort_downsweep', 'k_sort_upsweep',
+                                  'k_comp_fwd', 'k_comp_bwd', 'k_composite_train_fwd', 'k_composite_train_bwd', 'k_recon_loss',
+                                  'k_grad_check', 'k_march_count', 'k_march_emit', 'k_adam') if n in k), None)
         if not short:
             continue
         if short == 'k_field_fwd' and ('Lb1EEv9FieldArgs' in k or 'true>' in k):
@@ -65,5 +66,40 @@ def main(root, tag, samples_per_launch):
     print(json.dumps(out['kernels'].get('k_field_bwd'), indent=1))
 
 
+def sq_counters(root, tag):
+    """profiles/<tag>_sq_counters.json from a pass with
+    --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS"""
+    f = find(os.path.join(root, 'pmc_SQ'), 'p_counter_collection.csv')
+    if not f:
+        return
+    acc, n = collections.defaultdict(lambda: collections.defaultdict(float)), collections.Counter()
+    seen = set()
+    for r in csv.DictReader(open(f)):
+        k = r['Kernel_Name'].split('(')[0].replace('void ', '')
+        acc[k][r['Counter_Name']] += float(r['Counter_Value'])
+        if (k, r['Dispatch_Id']) not in seen:
+            seen.add((k, r['Dispatch_Id']))
+            n[k] += 1
+    out = {'source': 'rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS '
+                     'SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS -- python3 bench.py --steps 2 --warmup 1 '
+                     '--no-cpu-baseline --psnr-rays 0 (one pass; sums over the launches of a kernel)',
+           'units': 'fractions of SQ_WAVE_CYCLES (summed over waves): wait_any = parked in s_waitcnt, wait_inst_any = issue stall, '
+                    'active_any = executing; mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (4 * SQ_WAVE_CYCLES)',
+           'commit': subprocess.run(['git', 'rev-parse', '--short', 'HEAD'], capture_output=True, text=True).stdout.strip() or None,
+           'kernels': {}}
+    for k, v in acc.items():
+        w = v.get('SQ_WAVE_CYCLES', 0.0)
+        if w < 1e8 or not k.startswith(('k_', '_Z11k_field', 'k_field')) and 'k_field' not in k and 'k_comp' not in k:
+            continue
+        out['kernels'][k[:60]] = {'launches': n[k], 'SQ_WAVE_CYCLES': w, 'wait_any': round(v['SQ_WAIT_ANY'] / w, 3),
+                                  'wait_inst_any': round(v['SQ_WAIT_INST_ANY'] / w, 3), 'active_any': round(v['SQ_ACTIVE_INST_ANY'] / w, 3),
+                                  'active_valu': round(v['SQ_ACTIVE_INST_VALU'] / w, 3), 'active_lds': round(v['SQ_ACTIVE_INST_LDS'] / w, 4),
+                                  'wait_inst_lds': round(v['SQ_WAIT_INST_LDS'] / w, 4),
+                                  'mfma_busy': round(v['SQ_VALU_MFMA_BUSY_CYCLES'] / (4 * w), 3)}
+    with open('profiles/%s_sq_counters.json' % tag, 'w') as fo:
+        json.dump(out, fo, indent=1)
+
+
 if __name__ == '__main__':
     main(sys.argv[1], sys.argv[2], int(sys.argv[3]) if len(sys.argv) > 3 else 48565319)
+    sq_counters(sys.argv[1], sys.argv[2])
