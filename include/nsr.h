@@ -85,8 +85,10 @@ int nsr_packbits(const float *grid, uint32_t N, float density_thresh, uint8_t *b
  * counter [2] i32, noises [N] f32 or NULL (= zeros: perturb is force-disabled,
  * raymarching.py:247), z_hats [N] or NULL when !is_ndc.
  * Rays with offset+count >= M are dropped like the reference does (raymarching.cu:517).
- * workspace: nsr_march_rays_train_workspace_bytes(N) bytes of device scratch. */
-uint64_t nsr_march_rays_train_workspace_bytes(uint32_t N);
+ * workspace: nsr_march_rays_train_workspace_bytes(N, bound, max_steps) bytes of device scratch (per-ray counts, block sums
+ * and, for batches marched one thread per ray, a bit mask of bound * max_steps step indices per ray: the counting pass marks
+ * the samples, the emitting pass replays the t sequence without probing the grid again). */
+uint64_t nsr_march_rays_train_workspace_bytes(uint32_t N, float bound, uint32_t max_steps);
 int nsr_march_rays_train(const float *rays_o, const float *rays_d, const float *z_hats,
                          const uint8_t *grid, float bound, float dt_gamma, uint32_t max_steps,
                          int is_ndc, uint32_t N, uint32_t C, uint32_t H, uint32_t M,

@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get('NSR_LIB_PATH') or os.path.join(_HERE, 'libnsr_hip.so'
 
 NSR_F32, NSR_F16, NSR_BF16 = 0, 1, 2
 NSR_ACT_NONE, NSR_ACT_SIGMOID = 0, 1
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _DT = {torch.float32: NSR_F32, torch.float16: NSR_F16, torch.bfloat16: NSR_BF16}
 
@@ -44,7 +44,7 @@ SIGNATURES = {
     'nsr_morton3d': (i32, [vp, u32, vp, vp]),
     'nsr_morton3d_invert': (i32, [vp, u32, vp, vp]),
     'nsr_packbits': (i32, [vp, u32, f32, vp, vp]),
-    'nsr_march_rays_train_workspace_bytes': (u64, [u32]),
+    'nsr_march_rays_train_workspace_bytes': (u64, [u32, f32, u32]),
     'nsr_march_rays_train': (i32, [vp, vp, vp, vp, f32, f32, u32, i32, u32, u32, u32, u32, vp, vp, vp, vp, vp, vp,
                                    vp, vp, vp, vp]),
     'nsr_composite_rays_train_forward': (i32, [vp, vp, vp, vp, u32, u32, u32, f32, i32, vp, vp, vp, vp]),

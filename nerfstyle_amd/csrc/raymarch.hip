@@ -89,10 +89,12 @@ __device__ __forceinline__ bool rm_probe(const RmRay &r, const RmCfg &c, float t
     return occ;
 }
 
-__device__ __forceinline__ void rm_skip(const RmCfg &c, float &t, float tt) {
+// Returns the number of additions made (the march's step index k advances by it: k_march_count's sample mask).
+__device__ __forceinline__ uint32_t rm_skip(const RmCfg &c, float &t, float tt) {
 #pragma clang fp contract(off)
     // do { t += clamp(t * dt_gamma, dt_min, dt_max); } while (t < tt);  (:497) -- the same additions in the same
     // order, four per trip: the first partial sum that is not below tt is the loop's result
+    uint32_t adds = 0;
     for (;;) {
         const float t1 = t + rm_clamp(t * c.dt_gamma, c.dt_min, c.dt_max);
         const float t2 = t1 + rm_clamp(t1 * c.dt_gamma, c.dt_min, c.dt_max);
@@ -100,8 +102,10 @@ __device__ __forceinline__ void rm_skip(const RmCfg &c, float &t, float tt) {
         const float t4 = t3 + rm_clamp(t3 * c.dt_gamma, c.dt_min, c.dt_max);
         const bool b1 = t1 < tt, b2 = t2 < tt, b3 = t3 < tt, b4 = t4 < tt;
         t = !b1 ? t1 : (!b2 ? t2 : (!b3 ? t3 : t4));
+        adds += !b1 ? 1u : (!b2 ? 2u : (!b3 ? 3u : 4u));
         if (!(b1 && b2 && b3 && b4)) break;
     }
+    return adds;
 }
 
 __device__ __forceinline__ RmRay rm_load_ray(const float *rays_o, const float *rays_d, uint32_t n) {
@@ -185,7 +189,7 @@ __global__ void __launch_bounds__(RM_BLOCK)
 k_march_count(const float *__restrict__ rays_o, const float *__restrict__ rays_d, const uint8_t *__restrict__ grid,
               float bound, float dt_gamma, uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H,
               const float *__restrict__ nears, const float *__restrict__ fars, const float *__restrict__ noises,
-              uint32_t *__restrict__ counts, uint32_t *__restrict__ block_sums) {
+              uint32_t *__restrict__ counts, uint32_t *__restrict__ block_sums, uint32_t *__restrict__ mask, uint32_t kcap) {
     __shared__ uint32_t wave_sums[RM_BLOCK / 64];
     const uint32_t n = blockIdx.x * RM_BLOCK + threadIdx.x;
     uint32_t num_steps = 0;
@@ -200,13 +204,39 @@ k_march_count(const float *__restrict__ rays_o, const float *__restrict__ rays_d
             t += rm_clamp(t * dt_gamma, c.dt_min, c.dt_max) * noise;   // :452
         }
         float x, y, z, dt, tt;
-        while (t < far && num_steps < max_steps) {
-            if (rm_probe(r, c, t, x, y, z, dt, tt)) {
-                num_steps++;
-                t += dt;
-            } else {
-                rm_skip(c, t, tt);
+        if (mask == nullptr) {
+            while (t < far && num_steps < max_steps) {
+                if (rm_probe(r, c, t, x, y, z, dt, tt)) {
+                    num_steps++;
+                    t += dt;
+                } else {
+                    rm_skip(c, t, tt);
+                }
             }
+        } else {
+            // Round 3: the probes are made ONCE.  Every parameter the loop visits is an element of the occupancy-independent
+            // sequence t_0, t_{k+1} = t_k + clamp(t_k * dt_gamma, dt_min, dt_max) (both branches advance t by exactly that
+            // expression), so the samples are fully described by WHICH k they sit at: a bit mask per ray, word w of ray n at
+            // mask[w * N + n].  k_march_emit_mask replays the sequence (one addition per k, no probe) and emits the marked
+            // elements -- bit-identical to re-marching, at a twentieth of the instructions.
+            uint32_t k = 0, word = 0, wi = 0;
+            const uint32_t wmax = (kcap + 31u) / 32u;
+            while (t < far && num_steps < max_steps && k < kcap) {
+                if (rm_probe(r, c, t, x, y, z, dt, tt)) {
+                    word |= 1u << (k & 31u);
+                    num_steps++;
+                    t += dt;
+                    k++;
+                } else {
+                    k += rm_skip(c, t, tt);
+                }
+                while (wi < (k >> 5) && wi < wmax) {     // completed words (a skip may pass several: zeros)
+                    mask[(size_t)wi * N + n] = word;
+                    word = 0;
+                    wi++;
+                }
+            }
+            if (wi <= wmax) mask[(size_t)wi * N + n] = word;      // (the mask holds wmax + 1 words per ray)
         }
         counts[n] = num_steps;
     }
@@ -307,6 +337,66 @@ k_march_emit(const float *__restrict__ rays_o, const float *__restrict__ rays_d,
             step++;
         } else {
             rm_skip(c, t, tt);
+        }
+    }
+}
+
+// pass 2 without probes: replays the t sequence and emits the elements k_march_count marked (see there).  Not for NDC
+// (its deltas need the previous sample's z, k_march_emit keeps that form).
+__global__ void __launch_bounds__(RM_BLOCK)
+k_march_emit_mask(const float *__restrict__ rays_o, const float *__restrict__ rays_d, float bound, float dt_gamma,
+                  uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M, const float *__restrict__ nears,
+                  const float *__restrict__ noises, const uint32_t *__restrict__ counts, const uint32_t *__restrict__ block_bases,
+                  const uint32_t *__restrict__ mask, float *__restrict__ xyzs, float *__restrict__ dirs,
+                  float *__restrict__ deltas, int32_t *__restrict__ rays) {
+    __shared__ uint32_t wave_sums[RM_BLOCK / 64];
+    const uint32_t n = blockIdx.x * RM_BLOCK + threadIdx.x;
+    const uint32_t num_steps = n < N ? counts[n] : 0u;
+    uint32_t total;
+    const uint32_t point_index = block_bases[blockIdx.x] + rm_block_exclusive_scan(num_steps, wave_sums, total);
+    if (n >= N) return;
+    rays[n * 3 + 0] = (int32_t)n;
+    rays[n * 3 + 1] = (int32_t)point_index;
+    rays[n * 3 + 2] = (int32_t)num_steps;
+    if (num_steps == 0) return;
+    if (point_index + num_steps >= M) {          // :517, see k_march_emit
+        for (uint32_t i = point_index; i < min(point_index + num_steps, M); i++) {
+            xyzs[(size_t)i * 3 + 0] = 0.f; xyzs[(size_t)i * 3 + 1] = 0.f; xyzs[(size_t)i * 3 + 2] = 0.f;
+            if (dirs) { dirs[(size_t)i * 3 + 0] = 0.f; dirs[(size_t)i * 3 + 1] = 0.f; dirs[(size_t)i * 3 + 2] = 0.f; }
+            reinterpret_cast<float4 *>(deltas)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        return;
+    }
+    const RmCfg c = rm_cfg(bound, dt_gamma, max_steps, C, H, nullptr);
+    const RmRay r = rm_load_ray(rays_o, rays_d, n);
+    float t = nears[n];
+    {
+#pragma clang fp contract(off)
+        const float noise = noises ? noises[n] : 0.0f;
+        t += rm_clamp(t * dt_gamma, c.dt_min, c.dt_max) * noise;
+    }
+    float *pxyz = xyzs + (size_t)point_index * 3;
+    float *pdir = dirs ? dirs + (size_t)point_index * 3 : nullptr;
+    float *pdel = deltas + (size_t)point_index * 4;
+    uint32_t step = 0;
+    float last_t = t;
+    for (uint32_t w = 0; step < num_steps; w++) {
+        uint32_t word = mask[(size_t)w * N + n];
+        for (uint32_t b = 0; b < 32u && step < num_steps; b++, word >>= 1) {
+#pragma clang fp contract(off)
+            const float dt = rm_clamp(t * dt_gamma, c.dt_min, c.dt_max);
+            const float t_next = t + dt;
+            if (word & 1u) {
+                pxyz[0] = rm_clamp(r.ox + t * r.dx, -bound, bound);
+                pxyz[1] = rm_clamp(r.oy + t * r.dy, -bound, bound);
+                pxyz[2] = rm_clamp(r.oz + t * r.dz, -bound, bound);
+                if (pdir) { pdir[0] = r.dx; pdir[1] = r.dy; pdir[2] = r.dz; pdir += 3; }
+                reinterpret_cast<float2 *>(pdel)[0] = make_float2(dt, t_next - last_t);
+                last_t = t_next;
+                pxyz += 3; pdel += 4;
+                step++;
+            }
+            t = t_next;
         }
     }
 }
@@ -710,7 +800,7 @@ const char *nsr_status_string(int status) {
         default: return "unknown status";
     }
 }
-int nsr_abi_version(void) { return 3; }
+int nsr_abi_version(void) { return 4; }
 const char *nsr_target_arch(void) { return "gfx950"; }
 
 int nsr_near_far_from_aabb(const float *rays_o, const float *rays_d, const float *aabb, uint32_t N, float min_near,
@@ -745,9 +835,16 @@ int nsr_packbits(const float *grid, uint32_t N, float density_thresh, uint8_t *b
     return nsr_launch_status();
 }
 
-uint64_t nsr_march_rays_train_workspace_bytes(uint32_t N) {
+// step-index capacity of the sample mask: t runs from near to far (<= the AABB diagonal 2 sqrt(3) bound) in steps of at
+// least dt_min = 2 sqrt(3) / max_steps, i.e. at most bound * max_steps additions; + slack for the rounding of the sums
+static uint32_t march_kcap(float bound, uint32_t max_steps) { return (uint32_t)ceilf(fmaxf(bound, 1.0f) * (float)max_steps) + 96u; }
+static bool march_uses_mask(uint32_t N, int is_ndc) { return !is_ndc && N > NSR_MARCH_WPR_MAX_RAYS; }
+
+uint64_t nsr_march_rays_train_workspace_bytes(uint32_t N, float bound, uint32_t max_steps) {
     const uint64_t nblocks = (N + RM_BLOCK - 1) / RM_BLOCK;
-    return ((uint64_t)N + nblocks + 64) * sizeof(uint32_t);
+    uint64_t words = (uint64_t)N + nblocks + 64;
+    if (march_uses_mask(N, 0)) words += (uint64_t)N * ((march_kcap(bound, max_steps) + 31u) / 32u + 1u);
+    return words * sizeof(uint32_t);
 }
 
 int nsr_march_rays_train(const float *rays_o, const float *rays_d, const float *z_hats, const uint8_t *grid, float bound,
@@ -778,13 +875,22 @@ int nsr_march_rays_train(const float *rays_o, const float *rays_d, const float *
                            H, M, nears, fars, noises, counts, block_sums, xyzs, dirs, deltas, rays);
         return nsr_launch_status();
     }
+    // large batches, thread per ray: the counting pass marks the samples in a per-ray bit mask, the emitting pass replays the
+    // t sequence without probing the grid again (NDC keeps the re-marching emit)
+    const bool use_mask = !wpr && march_uses_mask(N, is_ndc);
+    uint32_t *mask = use_mask ? block_sums + nblocks + 64 : nullptr;
+    const uint32_t kcap = march_kcap(bound, max_steps);
     hipLaunchKernelGGL(k_march_count, dim3(nblocks), dim3(RM_BLOCK), 0, s, rays_o, rays_d, grid, bound, dt_gamma, max_steps, N,
-                       C, H, nears, fars, noises, counts, block_sums);
+                       C, H, nears, fars, noises, counts, block_sums, mask, kcap);
     // the reference's ray slots start at the incoming counter[1]; only 0 is supported without a
     // host read (renderer.py:213-214 zeroes the counter before every call)
     hipLaunchKernelGGL(k_scan_block_sums, dim3(1), dim3(1024), 0, s, block_sums, nblocks, counter, N);
-    hipLaunchKernelGGL(k_march_emit, dim3(nblocks), dim3(RM_BLOCK), 0, s, rays_o, rays_d, z_hats, grid, bound, dt_gamma,
-                       max_steps, is_ndc, N, C, H, M, nears, fars, noises, counts, block_sums, 0u, xyzs, dirs, deltas, rays);
+    if (use_mask)
+        hipLaunchKernelGGL(k_march_emit_mask, dim3(nblocks), dim3(RM_BLOCK), 0, s, rays_o, rays_d, bound, dt_gamma, max_steps, N, C,
+                           H, M, nears, noises, counts, block_sums, mask, xyzs, dirs, deltas, rays);
+    else
+        hipLaunchKernelGGL(k_march_emit, dim3(nblocks), dim3(RM_BLOCK), 0, s, rays_o, rays_d, z_hats, grid, bound, dt_gamma,
+                           max_steps, is_ndc, N, C, H, M, nears, fars, noises, counts, block_sums, 0u, xyzs, dirs, deltas, rays);
     return nsr_launch_status();
 }
 

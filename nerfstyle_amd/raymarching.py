@@ -68,8 +68,8 @@ def packbits(grid, thresh, bitfield=None):
     return bitfield
 
 
-def _march_workspace(N, device):
-    nbytes = int(L.lib().nsr_march_rays_train_workspace_bytes(N))
+def _march_workspace(N, device, bound, max_steps):
+    nbytes = int(L.lib().nsr_march_rays_train_workspace_bytes(N, float(bound), int(max_steps)))
     return torch.empty((nbytes + 3) // 4, dtype=torch.int32, device=device)
 
 
@@ -88,7 +88,7 @@ def march_rays_train_nosync(rays_o, rays_d, bound, density_bitfield, C, H, nears
     dirs = torch.empty(M, 3, dtype=torch.float32, device=dev) if want_dirs else None
     deltas = torch.empty(M, 4, dtype=torch.float32, device=dev)
     rays = torch.empty(N, 3, dtype=torch.int32, device=dev)
-    ws = _march_workspace(N, dev)
+    ws = _march_workspace(N, dev, bound, max_steps)
     with profiling.timed('march_train'):
         L.check(L.lib().nsr_march_rays_train(
             L.p(rays_o), L.p(rays_d), None, L.p(density_bitfield), float(bound), float(dt_gamma), int(max_steps), 0,
@@ -122,7 +122,7 @@ def march_rays_train(rays_o, rays_d, z_hats, bound, density_bitfield, C, H, near
     rays = torch.empty(N, 3, dtype=torch.int32, device=dev)
     if step_counter is None:
         step_counter = torch.zeros(2, dtype=torch.int32, device=dev)
-    ws = _march_workspace(N, dev)
+    ws = _march_workspace(N, dev, bound, max_steps)
     L.check(L.lib().nsr_march_rays_train(
         L.p(rays_o), L.p(rays_d), L.p(z_hats) if is_ndc else None, L.p(density_bitfield), float(bound),
         float(dt_gamma), int(max_steps), int(bool(is_ndc)), N, int(C), int(H), int(M), L.p(nears), L.p(fars),

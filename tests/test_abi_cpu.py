@@ -51,7 +51,8 @@ def test_host_only_entry_points(built):
     assert list(res) == list(O.grid_resolutions(16, O.grid_S(pls), 16))
     assert L.nsr_mlp_param_count(32, 1, 64, 1) == 3072 and L.nsr_mlp_param_count(16, 3, 64, 2) == 6144
     assert L.nsr_mlp_param_count(32, 5, 64, 1) == 3072
-    assert L.nsr_march_rays_train_workspace_bytes(4096) >= 4096 * 4
+    assert L.nsr_march_rays_train_workspace_bytes(4096, 2.0, 1024) >= 4096 * 4
+    assert L.nsr_march_rays_train_workspace_bytes(100000, 2.0, 1024) >= 100000 * 4 * (1 + 2048 // 32)
     assert L.nsr_compact_alive_workspace_bytes(1000) > 0
 
 

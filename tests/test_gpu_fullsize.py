@@ -54,7 +54,7 @@ def test_full_frame_762048_rays(O, dev):
     deltas = torch.full((M, 4), sent, dtype=torch.float32, device=dev)
     rays_info = torch.empty(N, 3, dtype=torch.int32, device=dev)
     counter = torch.zeros(2, dtype=torch.int32, device=dev)
-    ws_bytes = int(L.lib().nsr_march_rays_train_workspace_bytes(N))
+    ws_bytes = int(L.lib().nsr_march_rays_train_workspace_bytes(N, 2.0, cfg.max_steps))
     wsb = torch.empty((ws_bytes + 3) // 4, dtype=torch.int32, device=dev)
     L.check(L.lib().nsr_march_rays_train(L.p(rays.origins), L.p(rays.dirs), None, L.p(r.density_bitfield), 2.0, 0.0, cfg.max_steps,
                                          0, N, r.cascade, cfg.grid_size, M, L.p(nears), L.p(fars), L.p(xyzs), None, L.p(deltas),
