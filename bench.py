@@ -38,7 +38,7 @@ if ROOT not in sys.path:
 import numpy as np
 import torch
 
-PROFILE_JSON = os.path.join(ROOT, 'profiles', 'r02_pmc_traffic.json')
+PROFILE_JSON = os.path.join(ROOT, 'profiles', 'r03_pmc_traffic.json')
 
 
 def parse():
@@ -194,7 +194,7 @@ def profile_traffic(args):
 def profile_kernel_share(name, group):
     """TotalDurationNs of kernel `name` over that of the kernels in `group`, from the committed rocprofv3 summary (None if absent)."""
     import csv
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r02_bench_kernel_stats.csv')
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r03_bench_kernel_stats.csv')
     try:
         tot = {}
         with open(path) as f:
@@ -493,7 +493,7 @@ def run_recon(args, dev, rank, world):
                 # the HIP events bracket the PAIR (one C call launches both kernels): the scatter kernel's share of it comes
                 # from the committed rocprofv3 kernel summary of this command
                 share = profile_kernel_share('k_table_scatter', ('k_table_scatter', 'k_field_bwd'))
-                share_src = 'profiles/r02_bench_kernel_stats.csv' if share else None
+                share_src = 'profiles/r03_bench_kernel_stats.csv' if share else None
                 share = share or 1.0
             rate = k['atomic_requests_per_sample'] * samples / max(launches, 1) / (avg_ms * share * 1e-3) / 1e9
             extra['atomic_requests_bwd'] = {'bound': 'memory-side atomic unit', 'kernel': 'k_table_scatter' if sorted_bwd else 'k_field_bwd',
