@@ -44,8 +44,8 @@ PROFILE_JSON = os.path.join(ROOT, 'profiles', 'r03_pmc_traffic.json')
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--stage', choices=['recon', 'style'], default='recon')
     ap.add_argument('--scene', choices=['room', 'fern'], default='room')
     ap.add_argument('--rays-per-gpu', type=int, default=1008 * 756,
