@@ -228,3 +228,25 @@ def test_two_ranks_stylisation_iteration_equals_one_rank(tmp_path):
     assert float((ta[:, 1] - t1[:, 1]).abs().max()) <= 0.2 + 1e-6             # Adam step 1: |delta| = lr per touched entry
     assert float(((ta[:, 1] - t1[:, 1]).abs() > 1e-3).float().mean()) < 1e-3
 
+
+def test_bench_self_launches_two_ranks_from_a_plain_invocation(tmp_path):
+    """`python3 bench.py --gpus 2` WITHOUT torchrun (how the driver runs --gpus 1): bench.py decides from the environment, before
+    anything touches the GPU, to start the two rank processes itself; rank 0 prints the one JSON line with n_gpus = rccl_ranks = 2.
+    Rehearsed on one card over gloo (NSR_BENCH_BACKEND / NSR_BENCH_DEVICE); the data-parallel step is the real one: async
+    gradient all-reduce overlapped with the next step's march + sample sort, device-side GradScaler, fused Adam."""
+    import json
+    env = dict(os.environ, NSR_BENCH_BACKEND='gloo', NSR_BENCH_DEVICE='0', OMP_NUM_THREADS='2')
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1',
+                        '--rays-per-gpu', '150000', '--no-cpu-baseline', '--psnr-rays', '0'],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=420)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.strip().splitlines() if l.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['rccl_ranks'] == 2 and d['dist_backend'] == 'gloo' and d['scaling'] == 'weak'
+    assert d['steps'] == 3 and d['warmup'] == 1 and d['value'] > 0 and d['unit'] == 'Mrays/s'
+    assert d['config']['rays_per_step_per_gpu'] == 150000 and 'overlapped' in d['config']['parallelism']
+    assert d['config']['grad_scaler']['steps_taken'] == 4 and d['config']['grad_scaler']['steps_skipped'] == 0
+
