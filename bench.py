@@ -61,6 +61,11 @@ def parse():
     ap.add_argument('--no-patch-graphs', action='store_true', help='style stage: launch the patch kernels eagerly (host-bound) instead of replaying graphs')
     ap.add_argument('--fp32-loss', action='store_true', help='style stage: VGG + style loss in fp32 instead of autocast')
     ap.add_argument('--no-occ-update', action='store_true', help='leave the periodic occupancy update out of the step')
+    ap.add_argument('--occ-phase', choices=['steady', 'warmup'], default='steady',
+                    help="which phase of the reference's update schedule the timed steps are in: 'steady' = after the first "
+                         "update_thres (256) steps, partial updates (2 x H^3/4 sigma queries per cascade every 16 steps: what a training "
+                         "run spends all but its first 256 steps in; SURVEY 8d: 'steady state, after occupancy warm-up'); 'warmup' = "
+                         "the first 256 steps, full updates (C x H^3 queries)")
     ap.add_argument('--sort-samples', choices=['auto', 'on', 'off'], default='auto',
                     help="spatially ordered table scatter in the backward (nsr_sample_order): 'auto' = batches of >= 140 000 rays, dense pixel sets from 16 384")
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -174,6 +179,10 @@ def build(args, dev, rank):
         r.pin_march_bitfield(scene_bits)
         r.update_occ = True
     r.sort_samples = {'auto': 'auto', 'on': True, 'off': False}[args.sort_samples]
+    if r.update_occ and args.occ_phase == 'steady':
+        # one full update (the grid the partial updates refine), then continue the schedule from step update_thres on
+        r.update_state()
+        r.local_step = rcfg.update_thres
     return model, r, rcfg, torch.tensor(poses_np, device=dev), intr
 
 
@@ -533,8 +542,11 @@ def run_recon(args, dev, rank, world):
             'params': int(model.arena.numel()), 'parallelism': 'rays sharded x{} + RCCL all-reduce'.format(world) + (
                 " (async, overlapped with the next step's march + sample sort)" if world > 1 and graphed is None else ''),
             'occupancy_updates_in_timed_region': occ_updates,
-            'occupancy': ('device-side update every {} steps inside the step (full update: {} sigma queries); the march reads the seeded '
-                          'synthetic bitfield (random-init model has no scene)'.format(rcfg.update_iter, r.cascade * rcfg.grid_size ** 3)
+            'occupancy': ('device-side update every {} steps inside the step ({}); the march reads the seeded '
+                          'synthetic bitfield (random-init model has no scene)'.format(
+                              rcfg.update_iter, 'steady state of the schedule, local_step >= update_thres: partial updates, 2 x {} sigma queries per cascade'.format(
+                                  rcfg.grid_size ** 3 // 4) if args.occ_phase == 'steady' else 'first {} steps of the schedule: full updates, {} sigma queries'.format(
+                                  rcfg.update_thres, r.cascade * rcfg.grid_size ** 3))
                           if not args.no_occ_update else 'fixed synthetic bitfield, no update'),
             'table_scatter': ('spatial order (nsr_sample_order + stand-alone lattice scatter kernel)'
                               if r._use_spatial_order(n_rays, False) else 'ray order (run tracker, fused)'),
