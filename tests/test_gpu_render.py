@@ -13,7 +13,7 @@ from helpers import rel_l2, small_scene
 pytestmark = pytest.mark.gpu
 
 
-def _setup(dev, nc=5, table_dtype=torch.float32, table_scale=0.5, cap=None):
+def _setup(dev, nc=5, table_dtype=torch.float32, table_scale=0.5, cap=None, contrast=1.0):
     from nerfstyle_amd.common import BBox
     from nerfstyle_amd.config import NetworkConfig, RendererConfig
     from nerfstyle_amd.renderer import Renderer
@@ -21,6 +21,13 @@ def _setup(dev, nc=5, table_dtype=torch.float32, table_scale=0.5, cap=None):
     from nerfstyle_amd.style_nerf import StyleTCNerf
     from oracle import torch_port as TP
     ref = TP.Field(num_classes=nc, table_scale=table_scale)
+    if contrast != 1.0:
+        # the seeded checkpoint is nearly grey (rgb 0.50 +- 0.009, sigma 1.0 +- 0.09): scaling the last layers spreads the colours
+        # (std 0.13 at 16) and the densities (0.09 .. 11.7), so that an image comparison can tell a wrong MLP from a right one
+        with torch.no_grad():
+            ref.p_density[2048:] *= contrast
+            ref.p_color2[-1024:] *= contrast
+            ref.p_class[2048:] *= contrast
     m = StyleTCNerf(NetworkConfig(), BBox.from_radius(2.0), nc, enc_dtype=table_dtype, use_dir=False)
     sd = m.state_dict()
     sd.update({'x_density_embedder.embeddings': ref.emb_density.detach(), 'x_color_embedder.embeddings': ref.emb_color.detach(),
@@ -36,7 +43,7 @@ def _setup(dev, nc=5, table_dtype=torch.float32, table_scale=0.5, cap=None):
     return r, ref, poses, intr, bits
 
 
-def _oracle_render(O, ref, bits, ro, rd, half=None):
+def _oracle_render(O, ref, bits, ro, rd, half=None, density_scale=1.0):
     aabb = np.array([-2, -2, -2, 2, 2, 2], np.float32)
     near, far = O.near_far_from_aabb(ro, rd, aabb, 0.2)
     xyzs, _, deltas, rays, cnt = O.march_rays_train(ro, rd, 2.0, bits, 2, 128, near, far, 1024, align=128)
@@ -44,23 +51,34 @@ def _oracle_render(O, ref, bits, ro, rd, half=None):
                        ref.p_color1.detach().numpy(), ref.p_color2.detach().numpy(), ref.p_class.detach().numpy(), ref.offsets,
                        ref.pls, num_classes=ref.nc)
     out, sig, _ = O.field_forward(fp, xyzs, half=half)
-    ws, depth, image = O.composite_rays_train_forward(sig, out, deltas, rays, 1e-4)
+    ws, depth, image = O.composite_rays_train_forward((sig * np.float32(density_scale)).astype(np.float32), out, deltas, rays, 1e-4)
     rgb, d, classes = O.render_epilogue(ws, depth, image, near, far)
     return rgb, d, classes, int(cnt[0])
 
 
-def test_render_train_matches_oracle_pipeline(O, dev):
-    r, ref, poses, intr, bits = _setup(dev)
+@pytest.mark.parametrize('contrast,n_rays', [(1.0, 4096), (16.0, 2048)])
+def test_render_train_matches_oracle_pipeline(O, dev, contrast, n_rays):
+    """Training render (march -> fused field -> composite + epilogue) against the fp32 oracle pipeline on the same rays: PSNR > 45 dB
+    (bar: 40).  contrast = 16: the same checkpoint with its last layers scaled so that colours and densities really vary across
+    the image (the plain seeded checkpoint renders almost uniformly grey, which any MLP would pass)."""
+    r, ref, poses, intr, bits = _setup(dev, contrast=contrast)
+    if contrast != 1.0:
+        r.cfg.density_scale = 40.0                 # opaque surfaces: the image is the scene, not the white background
     np.random.seed(69420)
-    pix = np.random.choice(intr.w * intr.h, 4096, replace=False)
+    pix = np.random.choice(intr.w * intr.h, n_rays, replace=False)
     ro, rd = O.generate_rays(poses[0], intr.w, intr.h, intr.fx, intr.fy, intr.cx, intr.cy, 3, pix_indices=pix)
-    rgb_o, d_o, cls_o, m = _oracle_render(O, ref, bits, ro, rd)
-    assert m > 4096 * 8
+    rgb_o, d_o, cls_o, m = _oracle_render(O, ref, bits, ro, rd, density_scale=r.cfg.density_scale)
+    assert m > n_rays * 8
     out = r.render(torch.tensor(poses[0], device=dev), None, num_rays=None, training=True,
                    pix_subset=torch.tensor(pix, device=dev))
     rgb = out['rgb_map'].detach().cpu().numpy()
     psnr = O.compute_psnr(float(np.mean((rgb - rgb_o) ** 2)))
     assert psnr > 45.0, psnr
+    if contrast != 1.0:
+        hit = (1.0 - rgb_o.min(1)) > 0.05                                  # rays that see something
+        assert hit.mean() > 0.2 and rgb_o[hit].std() > 0.08, (hit.mean(), rgb_o[hit].std())      # the image is not flat
+        # ... and a wrong colour net is caught: shuffling the oracle's colour channels costs > 20 dB
+        assert O.compute_psnr(float(np.mean((rgb - rgb_o[:, ::-1]) ** 2))) < psnr - 20.0
     assert np.abs(out['classes'].detach().cpu().numpy() - cls_o).max() < 5e-2 * max(1.0, np.abs(cls_o).max())
     ok = np.isfinite(d_o)
     assert np.abs(out['trans_map'].detach().cpu().numpy()[ok] - d_o[ok]).max() < 5e-3
