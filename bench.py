@@ -357,7 +357,16 @@ def run_recon(args, dev, rank, world):
     # kernels, 0.2 ms -- an eighth of a 4 096-ray step) is drawn only when the previous one is used up.
     perm_state = {'perm': None, 'pos': 0}
 
+    tile_order = None
+    if n_rays == npix and os.environ.get('NSR_BENCH_PIXEL_ORDER', 'tiles') != 'random':
+        # a draw of EVERY pixel without replacement is the whole frame, in an order nothing depends on (the loss is a sum over
+        # the rays): the step visits the frame in 8x8-pixel tiles (nerfstyle_amd.rays.tile_order)
+        from nerfstyle_amd.rays import tile_order as _tile_order
+        tile_order = _tile_order(intr.w, intr.h, 8, 8, device=dev)
+
     def draw_pixels():
+        if tile_order is not None:
+            return tile_order
         if perm_state['perm'] is None or perm_state['pos'] + n_rays > npix:
             perm_state['perm'] = torch.randperm(npix, device=dev, generator=gen)
             perm_state['pos'] = 0
@@ -541,6 +550,8 @@ def run_recon(args, dev, rank, world):
             'num_classes': nc, 'table_dtype': args.table_dtype, 'mfma_dtype': args.compute_dtype,
             'params': int(model.arena.numel()), 'parallelism': 'rays sharded x{} + RCCL all-reduce'.format(world) + (
                 " (async, overlapped with the next step's march + sample sort)" if world > 1 and graphed is None else ''),
+            'pixel_order': ('every pixel of the frame once per step, visited in 8x8 tiles (a full draw without replacement: order-free)'
+                            if tile_order is not None else 'uniform draws without replacement (chunks of one device randperm of the frame)'),
             'occupancy_updates_in_timed_region': occ_updates,
             'occupancy': ('device-side update every {} steps inside the step ({}); the march reads the seeded '
                           'synthetic bitfield (random-init model has no scene)'.format(

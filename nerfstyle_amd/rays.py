@@ -57,3 +57,15 @@ def generate_rays(pose, intr: Intrinsics, img=None, patch: Optional[Box2D] = Non
     rays = RayBatch.__new__(RayBatch)    # directions are already unit length (normalised in-kernel)
     rays.origins, rays.dirs = rays_o, rays_d
     return rays, target
+
+
+def tile_order(w: int, h: int, tile_w: int = 8, tile_h: int = 8, device=None) -> torch.Tensor:
+    """Every pixel id of a w x h frame once, visited tile by tile (tile_w x tile_h pixels, row-major inside a tile and over the
+    tiles; edge tiles are partial).  For batches that cover the whole frame: `np.random.choice(w * h, w * h, replace=False)`
+    (nerf_lib.py:134) is the whole frame in an order the loss -- a sum over the rays -- does not depend on, and in THIS order the
+    64 rays of a marching wave cross the same occupancy cells, so the thread-per-ray march loop stops running both of its
+    branches for the longest of 64 unrelated rays (bench frame: march 2.37 -> 1.87 ms, step 36.1 -> 34.8 ms)."""
+    import numpy as np
+    yy, xx = np.divmod(np.arange(w * h, dtype=np.int64), w)
+    key = ((yy // tile_h) * ((w + tile_w - 1) // tile_w) + xx // tile_w) * (tile_w * tile_h) + (yy % tile_h) * tile_w + xx % tile_w
+    return torch.as_tensor(np.argsort(key, kind='stable'), device=device)

@@ -255,3 +255,15 @@ def test_resident_dataset_targets():
     assert rgb_only.targets.shape == (n, h * w, 3)
     with pytest.raises(ValueError):
         ResidentDataset(images[:, :, :-1], poses[:n], intr, 2.0, 'cpu')
+
+
+def test_tile_order_is_a_permutation_of_the_frame_in_tiles():
+    from nerfstyle_amd.rays import tile_order
+    for w, h, tw, th in ((1008, 756, 8, 8), (37, 21, 8, 8), (16, 16, 4, 2)):
+        p = tile_order(w, h, tw, th).numpy()
+        assert np.array_equal(np.sort(p), np.arange(w * h))
+        y, x = np.divmod(p, w)
+        tid = (y // th) * ((w + tw - 1) // tw) + x // tw
+        assert np.all(np.diff(tid) >= 0)                                    # tile after tile
+        first = p[:min(tw, w) * min(th, h)]
+        assert np.array_equal(first, (np.arange(min(th, h))[:, None] * w + np.arange(min(tw, w))[None, :]).reshape(-1))
