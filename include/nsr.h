@@ -87,7 +87,8 @@ int nsr_packbits(const float *grid, uint32_t N, float density_thresh, uint8_t *b
  * Rays with offset+count >= M are dropped like the reference does (raymarching.cu:517).
  * workspace: nsr_march_rays_train_workspace_bytes(N, bound, max_steps) bytes of device scratch (per-ray counts, block sums
  * and, for batches marched one thread per ray, a bit mask of bound * max_steps step indices per ray: the counting pass marks
- * the samples, the emitting pass replays the t sequence without probing the grid again). */
+ * the samples, the emitting pass replays the t sequence without probing the grid again; batches marched one wave per ray
+ * record the start and the 64-bit sample mask of every 64-step block instead, and their emit replays those). */
 uint64_t nsr_march_rays_train_workspace_bytes(uint32_t N, float bound, uint32_t max_steps);
 int nsr_march_rays_train(const float *rays_o, const float *rays_d, const float *z_hats,
                          const uint8_t *grid, float bound, float dt_gamma, uint32_t max_steps,

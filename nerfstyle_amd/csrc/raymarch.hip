@@ -424,13 +424,47 @@ k_march_block_sums(const uint32_t *__restrict__ counts, uint32_t N, uint32_t *__
     if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
 }
 
+// The 64 consecutive march parameters that start at t_block -- lane j gets t_j of t_0 = t_block, t_{j+1} = t_j + clamp(t_j *
+// dt_gamma, dt_min, dt_max) -- and t_64 (the next block's start).  Shared by the counting / re-marching kernel and the replaying
+// emit, so that both see the same floats.
+__device__ __forceinline__ void wpr_block_t(const RmCfg &c, float dt_gamma, float t_block, uint32_t lane, float &my_t, float &t_next) {
+    float tc = t_block;
+    my_t = t_block;
+    bool closed = false;
+    if (dt_gamma == 0.0f && t_block > 0.0f) {
+        // Constant step (LLFF: dt_gamma = 0): t_{j+1} = fl(t_j + dt).  Inside one binade every t_j is a multiple of the
+        // binade's ulp u, so the rounded sum advances the BIT PATTERN by a constant c = dt / u rounded to an integer (ties
+        // to even make the very first step the only possible exception: after it the mantissa parity repeats).  Two real
+        // additions give t_1 and t_2, c = bits(t_2) - bits(t_1), and t_j = bits(t_1) + (j - 1) c for j = 1..64 -- the same
+        // floats as the 64 serial additions below, as long as t_1 .. t_64 share an exponent (else: the serial loop).
+#pragma clang fp contract(off)
+        const float dt0 = rm_clamp(t_block * dt_gamma, c.dt_min, c.dt_max);
+        const float t1 = t_block + dt0, t2 = t1 + dt0;
+        const uint32_t b1 = __float_as_uint(t1), b2 = __float_as_uint(t2), cc = b2 - b1;
+        const uint32_t b64 = b1 + 63u * cc;
+        if (b2 > b1 && (b1 >> 23) == (b64 >> 23) && cc < (1u << 23)) {
+            closed = true;
+            my_t = lane == 0 ? t_block : __uint_as_float(b1 + (lane - 1u) * cc);
+            tc = __uint_as_float(b64);
+        }
+    }
+    if (!closed) {
+#pragma clang fp contract(off)
+        for (uint32_t j = 0; j < 64; j++) {
+            if (lane == j) my_t = tc;
+            tc += rm_clamp(tc * dt_gamma, c.dt_min, c.dt_max);
+        }
+    }
+    t_next = tc;
+}
+
 template <bool EMIT>
 __global__ void __launch_bounds__(256)
 k_march_wpr(const float *__restrict__ rays_o, const float *__restrict__ rays_d, const uint8_t *__restrict__ grid, float bound,
             float dt_gamma, uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M, const float *__restrict__ nears,
             const float *__restrict__ fars, const float *__restrict__ noises, uint32_t *__restrict__ counts,
             const uint32_t *__restrict__ block_bases, float *__restrict__ xyzs, float *__restrict__ dirs,
-            float *__restrict__ deltas, int32_t *__restrict__ rays) {
+            float *__restrict__ deltas, int32_t *__restrict__ rays, uint32_t *__restrict__ slots, uint32_t slot_cap) {
     __shared__ float t_lds[4][64];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t n = blockIdx.x * 4 + wave;
@@ -474,34 +508,14 @@ k_march_wpr(const float *__restrict__ rays_o, const float *__restrict__ rays_d, 
     float carry_tt = -INFINITY;       // the walk enters a block at its first t >= carry_tt
     float last_t = t_block;           // :530, t after the previous sample's step
     bool done = false;
-    while (!done && t_block < far) {
-        // ---- the block's 64 parameters: every lane runs the serial recurrence and keeps its own ----
-        float my_t = t_block, tc = t_block;
-        bool closed = false;
-        if (dt_gamma == 0.0f && t_block > 0.0f) {
-            // Constant step (LLFF: dt_gamma = 0): t_{j+1} = fl(t_j + dt).  Inside one binade every t_j is a multiple of the
-            // binade's ulp u, so the rounded sum advances the BIT PATTERN by a constant c = dt / u rounded to an integer (ties
-            // to even make the very first step the only possible exception: after it the mantissa parity repeats).  Two real
-            // additions give t_1 and t_2, c = bits(t_2) - bits(t_1), and t_j = bits(t_1) + (j - 1) c for j = 1..64 -- the same
-            // floats as the 64 serial additions below, as long as t_1 .. t_64 share an exponent (else: the serial loop).
-#pragma clang fp contract(off)
-            const float dt0 = rm_clamp(t_block * dt_gamma, c.dt_min, c.dt_max);
-            const float t1 = t_block + dt0, t2 = t1 + dt0;
-            const uint32_t b1 = __float_as_uint(t1), b2 = __float_as_uint(t2), cc = b2 - b1;
-            const uint32_t b64 = b1 + 63u * cc;
-            if (b2 > b1 && (b1 >> 23) == (b64 >> 23) && cc < (1u << 23)) {
-                closed = true;
-                my_t = lane == 0 ? t_block : __uint_as_float(b1 + (lane - 1u) * cc);
-                tc = __uint_as_float(b64);
-            }
-        }
-        if (!closed) {
-#pragma clang fp contract(off)
-            for (uint32_t j = 0; j < 64; j++) {
-                if (lane == j) my_t = tc;
-                tc += rm_clamp(tc * dt_gamma, c.dt_min, c.dt_max);
-            }
-        }
+    // (counting pass with `slots`: every block's start and sample mask are recorded -- [slot_cap][3] words per ray after the N
+    // block counts -- and k_march_wpr_replay emits from them without probing again; slot_cap * 64 >= march_kcap, the bound the
+    // thread-per-ray mask relies on)
+    uint32_t nblk = 0;
+    while (!done && t_block < far && (EMIT || slots == nullptr || nblk < slot_cap)) {
+        // ---- the block's 64 parameters ----
+        float my_t, tc;
+        wpr_block_t(c, dt_gamma, t_block, lane, my_t, tc);
         const float t_next_block = tc;
         // ---- speculative probe ----
         const bool valid = my_t < far;
@@ -564,9 +578,103 @@ k_march_wpr(const float *__restrict__ rays_o, const float *__restrict__ rays_d, 
             last_t = tl[63 - __builtin_clzll(sample_mask)];
         }
         __builtin_amdgcn_wave_barrier();
+        if (!EMIT && slots != nullptr) {
+            if (lane < 3) {
+                const uint32_t wv = lane == 0 ? __float_as_uint(t_block) : (lane == 1 ? (uint32_t)sample_mask : (uint32_t)(sample_mask >> 32));
+                slots[(size_t)N + ((size_t)n * slot_cap + nblk) * 3 + lane] = wv;
+            }
+            nblk++;
+        }
         t_block = t_next_block;
     }
-    if (!EMIT && lane == 0) counts[n] = steps;
+    if (!EMIT && lane == 0) {
+        counts[n] = steps;
+        if (slots != nullptr) slots[n] = nblk;
+    }
+}
+
+// Emitting pass of the wave-per-ray march from the counting pass's records: no occupancy probe, no successor search, no chain
+// walk -- per recorded block with samples: the 64 parameters again (wpr_block_t), positions and step sizes of the marked lanes,
+// the same stores as k_march_wpr<true>.  Bit-identical output; 4 096-ray bf16 + graph step 1.09 -> 0.96 ms.
+__global__ void __launch_bounds__(256)
+k_march_wpr_replay(const float *__restrict__ rays_o, const float *__restrict__ rays_d, float bound, float dt_gamma, uint32_t max_steps,
+                   uint32_t N, uint32_t C, uint32_t H, uint32_t M, const uint32_t *__restrict__ counts,
+                   const uint32_t *__restrict__ block_bases, const uint32_t *__restrict__ slots, uint32_t slot_cap,
+                   float *__restrict__ xyzs, float *__restrict__ dirs, float *__restrict__ deltas, int32_t *__restrict__ rays) {
+    __shared__ float t_lds[4][64];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t n = blockIdx.x * 4 + wave;
+    if (n >= N) return;                                     // wave-uniform
+    float *tl = t_lds[wave];
+    const RmCfg c = rm_cfg(bound, dt_gamma, max_steps, C, H, nullptr);
+    const RmRay r = rm_load_ray(rays_o, rays_d, n);
+    const uint32_t blk0 = (n / RM_BLOCK) * RM_BLOCK;
+    uint32_t part = 0;
+    for (uint32_t i = blk0 + lane; i < n; i += 64) part += counts[i];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) part += __shfl_xor(part, off, 64);
+    const uint32_t point_index = block_bases[n / RM_BLOCK] + part;
+    const uint32_t limit = counts[n];
+    if (lane == 0) {
+        rays[n * 3 + 0] = (int32_t)n;
+        rays[n * 3 + 1] = (int32_t)point_index;
+        rays[n * 3 + 2] = (int32_t)limit;
+    }
+    if (limit == 0) return;
+    if (point_index + limit >= M) {          // :517; zero the in-buffer part of a dropped ray (see k_march_emit)
+        for (uint32_t i = point_index + lane; i < min(point_index + limit, M); i += 64) {
+            xyzs[(size_t)i * 3 + 0] = 0.f; xyzs[(size_t)i * 3 + 1] = 0.f; xyzs[(size_t)i * 3 + 2] = 0.f;
+            if (dirs) { dirs[(size_t)i * 3 + 0] = 0.f; dirs[(size_t)i * 3 + 1] = 0.f; dirs[(size_t)i * 3 + 2] = 0.f; }
+            reinterpret_cast<float4 *>(deltas)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        return;
+    }
+    const uint32_t nblk = min(slots[n], min(slot_cap, 64u));
+    // lane b holds block b's record
+    const uint32_t *rec = slots + (size_t)N + (size_t)n * slot_cap * 3;
+    uint32_t s_t = 0, s_lo = 0, s_hi = 0;
+    if (lane < nblk) { s_t = rec[lane * 3]; s_lo = rec[lane * 3 + 1]; s_hi = rec[lane * 3 + 2]; }
+    uint32_t steps = 0;
+    float last_t = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)s_t));      // block 0 starts at the ray's first parameter
+    for (uint32_t b = 0; b < nblk; b++) {
+        const unsigned long long sample_mask = (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)s_lo, (int)b) |
+                                               ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)s_hi, (int)b) << 32);
+        if (sample_mask == 0ull) continue;
+        const float t_block = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)s_t, (int)b));
+        float my_t, t_next;
+        wpr_block_t(c, dt_gamma, t_block, lane, my_t, t_next);
+        steps += (uint32_t)__popcll(sample_mask);
+        float x, y, z, dt, t_after;
+        {
+#pragma clang fp contract(off)
+            x = rm_clamp(r.ox + my_t * r.dx, -c.bound, c.bound);         // rm_probe's expressions
+            y = rm_clamp(r.oy + my_t * r.dy, -c.bound, c.bound);
+            z = rm_clamp(r.oz + my_t * r.dz, -c.bound, c.bound);
+            dt = rm_clamp(my_t * c.dt_gamma, c.dt_min, c.dt_max);
+            t_after = my_t + dt;                                            // t += dt, :551
+        }
+        const bool mine = (sample_mask >> lane) & 1ull;
+        const uint32_t before = (uint32_t)__popcll(sample_mask & ((1ull << lane) - 1ull));
+        const uint32_t first_idx = steps - (uint32_t)__popcll(sample_mask);
+        __builtin_amdgcn_wave_barrier();
+        tl[lane] = t_after;
+        __builtin_amdgcn_wave_barrier();
+        const unsigned long long below = sample_mask & ((1ull << lane) - 1ull);
+        const float prev_t = below ? tl[63 - __builtin_clzll(below)] : last_t;
+        if (mine) {
+            const size_t o = (size_t)point_index + first_idx + before;
+            xyzs[o * 3 + 0] = x; xyzs[o * 3 + 1] = y; xyzs[o * 3 + 2] = z;
+            if (dirs) { dirs[o * 3 + 0] = r.dx; dirs[o * 3 + 1] = r.dy; dirs[o * 3 + 2] = r.dz; }
+            float dprev;
+            {
+#pragma clang fp contract(off)
+                dprev = t_after - prev_t;
+            }
+            reinterpret_cast<float2 *>(deltas + o * 4)[0] = make_float2(dt, dprev);
+        }
+        last_t = tl[63 - __builtin_clzll(sample_mask)];
+        __builtin_amdgcn_wave_barrier();
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -839,11 +947,17 @@ int nsr_packbits(const float *grid, uint32_t N, float density_thresh, uint8_t *b
 // least dt_min = 2 sqrt(3) / max_steps, i.e. at most bound * max_steps additions; + slack for the rounding of the sums
 static uint32_t march_kcap(float bound, uint32_t max_steps) { return (uint32_t)ceilf(fmaxf(bound, 1.0f) * (float)max_steps) + 96u; }
 static bool march_uses_mask(uint32_t N, int is_ndc) { return !is_ndc && N > NSR_MARCH_WPR_MAX_RAYS; }
+// wave-per-ray path: records per ray (block start + 64-bit sample mask), 0 = too many for a wave's lanes (re-marching emit)
+static uint32_t march_wpr_slot_cap(float bound, uint32_t max_steps) {
+    const uint32_t cap = (march_kcap(bound, max_steps) + 63u) / 64u + 1u;
+    return cap <= 64u ? cap : 0u;
+}
 
 uint64_t nsr_march_rays_train_workspace_bytes(uint32_t N, float bound, uint32_t max_steps) {
     const uint64_t nblocks = (N + RM_BLOCK - 1) / RM_BLOCK;
     uint64_t words = (uint64_t)N + nblocks + 64;
     if (march_uses_mask(N, 0)) words += (uint64_t)N * ((march_kcap(bound, max_steps) + 31u) / 32u + 1u);
+    else words += (uint64_t)N * (1u + 3u * march_wpr_slot_cap(bound, max_steps));
     return words * sizeof(uint32_t);
 }
 
@@ -866,13 +980,23 @@ int nsr_march_rays_train(const float *rays_o, const float *rays_d, const float *
     const bool wpr = !is_ndc && (wpr_env >= 0 ? wpr_env != 0 : N <= NSR_MARCH_WPR_MAX_RAYS);
     if (wpr) {
         const uint32_t wblocks = (N + 3) / 4;
+        // the counting pass records every block's start and sample mask; the emit replays them (no second probe).  The records
+        // need the workspace of nsr_march_rays_train_workspace_bytes for THIS N (a forced wave-per-ray march of a large batch,
+        // NSR_MARCH_WPR=1, re-marches instead: its workspace was sized for the thread-per-ray mask)
+        static const int slots_env = [] { const char *e = getenv("NSR_MARCH_WPR_SLOTS"); return e ? atoi(e) : 1; }();
+        const uint32_t slot_cap = (slots_env && !march_uses_mask(N, 0)) ? march_wpr_slot_cap(bound, max_steps) : 0u;
+        uint32_t *slots = slot_cap ? block_sums + nblocks + 64 : nullptr;
         hipLaunchKernelGGL((k_march_wpr<false>), dim3(wblocks), dim3(256), 0, s, rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C,
                            H, M, nears, fars, noises, counts, (const uint32_t *)nullptr, (float *)nullptr, (float *)nullptr,
-                           (float *)nullptr, (int32_t *)nullptr);
+                           (float *)nullptr, (int32_t *)nullptr, slots, slot_cap);
         hipLaunchKernelGGL(k_march_block_sums, dim3(nblocks), dim3(RM_BLOCK), 0, s, counts, N, block_sums);
         hipLaunchKernelGGL(k_scan_block_sums, dim3(1), dim3(1024), 0, s, block_sums, nblocks, counter, N);
-        hipLaunchKernelGGL((k_march_wpr<true>), dim3(wblocks), dim3(256), 0, s, rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C,
-                           H, M, nears, fars, noises, counts, block_sums, xyzs, dirs, deltas, rays);
+        if (slots)
+            hipLaunchKernelGGL(k_march_wpr_replay, dim3(wblocks), dim3(256), 0, s, rays_o, rays_d, bound, dt_gamma, max_steps, N, C, H, M,
+                               counts, block_sums, slots, slot_cap, xyzs, dirs, deltas, rays);
+        else
+            hipLaunchKernelGGL((k_march_wpr<true>), dim3(wblocks), dim3(256), 0, s, rays_o, rays_d, grid, bound, dt_gamma, max_steps, N,
+                               C, H, M, nears, fars, noises, counts, block_sums, xyzs, dirs, deltas, rays, (uint32_t *)nullptr, 0u);
         return nsr_launch_status();
     }
     // large batches, thread per ray: the counting pass marks the samples in a per-ray bit mask, the emitting pass replays the
