@@ -335,7 +335,7 @@ def run_recon(args, dev, rank, world):
         # trainers/base.py:251-304: MSE + 0.001 * cross-entropy on the class logits -- one fused kernel for value and gradient
         # (nsr_recon_loss: target gather, loss scale and 1 / world folded in)
         total = recon_loss(out['rgb_map'], out['classes'], target_rgb, target_cls, pix, ce_lambda=1e-3, factor=1.0 / world,
-                           scale=scale_t if scale_t is not None else loss_scale_t)
+                           scale=scale_t if scale_t is not None else loss_scale_t, backward=os.environ.get('NSR_BENCH_LOSS_BACKWARD', '1') != '0')
         if sp_lambda > 0:
             # trainers/base.py:409-413: sigma of 50 000 uniform points of the bbox, WITH autograd; :285-291: the loss
             pts = torch.rand(sp_n, 3, device=dev, generator=gen) * 4.0 - 2.0
@@ -399,7 +399,8 @@ def run_recon(args, dev, rank, world):
             out = r.finish_train(ctx)
             cnt = r._last_counter           # this render's device-side sample count
             loss = loss_fn(out, pix)
-            loss.backward()
+            if loss.requires_grad:         # the sparsity term; the reconstruction loss has back-propagated itself
+                loss.backward()
         if world > 1:
             sync = P.sync_gradients_async(model, optimizer=opt)
             if graphed is None and it < last_it and not r.occupancy_update_due():

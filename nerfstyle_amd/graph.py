@@ -55,7 +55,8 @@ class GraphedRenderStep:
         finally:
             self.r.update_occ = keep
         loss = self.loss_fn(out, self.pix)
-        loss.backward()
+        if loss.requires_grad:             # (recon_loss(..., backward=True) has back-propagated already)
+            loss.backward()
         if with_optimizer and self.optimizer is not None:
             self.optimizer.step(scaler=self.scaler, lr_decay_steps=self.lr_decay_steps)
         return loss.detach()

@@ -15,6 +15,7 @@ from . import _lib as L
 class _recon_loss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, rgb_map, classes, target_rgb, target_cls, pix, ce_lambda, factor, scale):
+        ctx.set_materialize_grads(False)
         N = rgb_map.shape[0]
         dev = rgb_map.device
         rgb_map = rgb_map.detach().to(torch.float32).contiguous()
@@ -42,18 +43,39 @@ class _recon_loss(torch.autograd.Function):
     @staticmethod
     def backward(ctx, go):
         g_rgb, g_cls = ctx.saved_tensors
+        if go is None:
+            return (None,) * 8
         # the stored gradients already carry scale * factor; `go` is 1 for loss.backward()
         return g_rgb * go, (g_cls * go if g_cls is not None else None), None, None, None, None, None, None
 
 
-def recon_loss(rgb_map, classes, target_rgb, target_cls=None, pix=None, ce_lambda=1e-3, factor=1.0, scale=None):
+def recon_loss(rgb_map, classes, target_rgb, target_cls=None, pix=None, ce_lambda=1e-3, factor=1.0, scale=None, backward=False):
     """-> 0-dim loss tensor = factor * scale * (mse + ce_lambda * ce).  rgb_map [N,3], classes [N,nc] (or None) from
     Renderer.render(training=True); target_rgb [P,3] f32 / target_cls [P] int64 resident on the device, pix [N] int64 their rows
-    (None: P == N, row n).  scale: 0-dim float32 device tensor (LossScaler.scale_tensor) or None."""
-    return _recon_loss.apply(rgb_map, classes, target_rgb, target_cls, pix, ce_lambda, factor, scale)
+    (None: P == N, row n).  scale: 0-dim float32 device tensor (LossScaler.scale_tensor) or None.
+    backward=True: the gradient the kernel has just written is back-propagated from here -- autograd.backward(outputs of the
+    renderer, d loss / d outputs) -- and the returned loss is detached: `loss.backward()` on the plain form costs a ones-fill and
+    one multiply per stored gradient (three launches, 1.5 % of a 4 096-ray captured step) to apply a factor that is 1."""
+    loss = _recon_loss.apply(rgb_map, classes, target_rgb, target_cls, pix, ce_lambda, factor, scale)
+    if not backward or loss.grad_fn is None:
+        return loss
+    g_rgb, g_cls = loss.grad_fn.saved_tensors
+    outs, grads = [rgb_map], [g_rgb]
+    if g_cls is not None and classes is not None and classes.requires_grad:
+        outs.append(classes)
+        grads.append(g_cls)
+    if not rgb_map.requires_grad:
+        outs, grads = outs[1:], grads[1:]
+    if outs:
+        torch.autograd.backward(outs, grads)
+    det = loss.detach()
+    det._nsr_terms = loss.grad_fn.terms
+    return det
 
 
 def last_terms(loss):
     """(mse, ce_lambda * ce) of a loss returned by recon_loss, unscaled, as a device tensor [2] (no host sync)."""
+    if hasattr(loss, '_nsr_terms'):
+        return loss._nsr_terms[1:]
     fn = loss.grad_fn
     return fn.terms[1:] if fn is not None and hasattr(fn, 'terms') else None

@@ -373,6 +373,7 @@ class _render_train_fn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, sigmas, rgbs, deltas, rays, nears, fars, T_thresh):
+        ctx.set_materialize_grads(False)     # outputs the loss does not use arrive as None, not as zero tensors (two fills a step)
         from . import _lib as L
         from . import profiling
         M, N, C = sigmas.shape[0], rays.shape[0], rgbs.shape[1]

@@ -219,6 +219,13 @@ def test_recon_loss_value_and_gradient_equal_torch(dev):
         assert abs(terms[0] - float(mse)) < 2e-6 * float(mse) and abs(terms[1] - float(ce)) < 2e-6 * float(ce)
         assert float((rgb.grad - rgb2.grad).abs().max()) < 1e-6 * float(rgb2.grad.abs().max())
         assert float((cls.grad - cls2.grad).abs().max()) < 1e-6 * float(cls2.grad.abs().max()) + 1e-12
+        # backward=True: the stored gradient is back-propagated from inside the call (through whatever produced the inputs)
+        # and the loss comes back detached -- same value, same terms, bit-identical gradients
+        base_r, base_c = rgb.detach().clone().requires_grad_(), cls.detach().clone().requires_grad_()
+        l3 = recon_loss(base_r * 1.0, base_c * 1.0, t_rgb, t_cls, pix, ce_lambda=1e-3, factor=0.5, scale=scale, backward=True)
+        assert not l3.requires_grad and float(l3) == float(loss)
+        assert torch.equal(last_terms(l3), last_terms(loss))
+        assert torch.equal(base_r.grad, rgb.grad) and torch.equal(base_c.grad, cls.grad)
     # MSE only, no pixel indirection
     rgb = torch.rand(1000, 3, device=dev, generator=g).requires_grad_()
     tgt = torch.rand(1000, 3, device=dev, generator=g)
