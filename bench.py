@@ -608,7 +608,7 @@ def run_style(args, dev, rank, world):
     scaler = LossScaler(init_scale=65536.0, enabled=(args.compute_dtype == 'f16'))
     loss_scale = scaler.scale_tensor(dev)
     n_patches = len(patch_list(W, H, 200))
-    patch_graphs = None if args.no_patch_graphs else {}                        # pass 2: one hipGraph per patch shape (graph.GraphedPatchBackward)
+    patch_graphs = None if args.no_patch_graphs else {'streams': int(os.environ.get('NSR_PATCH_STREAMS', '4'))}                        # pass 2: one hipGraph per patch shape (graph.GraphedPatchBackward)
     total_samples = torch.zeros(1, dtype=torch.int64, device=dev)
 
     def step(it):
@@ -666,7 +666,7 @@ def run_style(args, dev, rank, world):
                          "semantic-NNFM loss (PyTorch, {}) + {} {} deferred-backprop patches of 200x200, colour table only, max_steps {}; "
                          "random seeded VGG weights, style image and segment maps (none exist offline)").format(
                              args.scene, W, H, 'fp32' if args.fp32_loss else 'autocast ' + args.compute_dtype, n_patches,
-                             'eager' if args.no_patch_graphs else 'graph-replayed', rcfg.max_steps),
+                             'eager' if args.no_patch_graphs else 'graph-replayed ({} streams)'.format(patch_graphs.get('streams', 4)), rcfg.max_steps),
             'rays_per_step': W * H, 'patches': n_patches, 'max_steps': rcfg.max_steps, 'num_classes': nc,
             'table_dtype': args.table_dtype, 'mfma_dtype': args.compute_dtype,
             'parallelism': 'patches + pass-1 pixel rows sharded x{}, packed colour-table gradient all-reduce'.format(world),

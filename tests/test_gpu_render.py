@@ -959,16 +959,21 @@ def test_graphed_patch_backward_equals_eager(O, dev):
         deferred_backprop_step(r, pose, image_loss, patch_size=200, loss_scale=1024.0, patch_graphs=graphs)
         return m.arena.grad.clone()
 
-    graphs = {}
+    from nerfstyle_amd.graph import GraphedPatchBackward
+    graphs, serial = {}, {'concurrent': False}
     for it in (0, 3):
         pose = torch.tensor(poses[it], device=dev)
         g_eager = run(None, pose)
-        g_graph = run(graphs, pose)
+        g_graph = run(graphs, pose)            # replays alternate between the caller's stream and a side stream
+        g_serial = run(serial, pose)           # one stream, one graph per shape
         assert float(g_eager.abs().sum()) > 0
         assert rel_l2(g_graph.cpu().numpy(), g_eager.cpu().numpy()) < 1e-5, it
+        assert rel_l2(g_serial.cpu().numpy(), g_eager.cpu().numpy()) < 1e-5, it
         gt = g_graph[:m.table_elems].view(m.rows, 2, 2)
         assert float(gt[:, 0].abs().max()) == 0.0 and float(gt[:, 1].abs().max()) > 0.0
-    assert len(graphs) == 4
+    # 6 patches of 4 shapes: one graph per (shape, stream slot) they fell on / per shape
+    assert sum(isinstance(v, GraphedPatchBackward) for v in graphs.values()) == 6
+    assert sum(isinstance(v, GraphedPatchBackward) for v in serial.values()) == 4
 
 
 def test_style_criterion_autocast_close_to_fp32(dev):
