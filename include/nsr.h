@@ -272,7 +272,9 @@ int nsr_field_forward(const nsr_field_desc *desc, const void *tables, const floa
  * masks, MLP dgrad on MFMA, wgrad on MFMA (accumulated into grad_mlp), and scatters the
  * encoder gradient into grad_tables with fp32 atomics (both encoders per request).
  * train_density_table / train_color_table: 0 skips that encoder's scatter (stylisation
- * optimises x_color_embedder only, trainers/style.py:25). */
+ * optimises x_color_embedder only, trainers/style.py:25).  grad_mlp may be NULL: no weight gradient is produced; with perm,
+ * saved feats, train_density_table = 0 and grad_mlp = NULL (exactly the stylisation stage) a colour-only kernel runs that
+ * computes the class / colour nets' input gradients and nothing else. */
 int nsr_field_backward(const nsr_field_desc *desc, const void *tables, const float *mlp_params,
                        const float *xyzs, uint32_t M, const int32_t *m_dev, const float *grad_sigmas,
                        const float *grad_rgbs, float *grad_tables, float *grad_mlp,

@@ -1223,10 +1223,140 @@ static int field_bwd_launch_variant(const FieldBwdArgs &b, int table_dtype, int 
 int nsr_field_bwd_launch_gout(const FieldBwdArgs &b, int table_dtype, int compute_dtype, bool feats, dim3 grid, hipStream_t s);
 
 #ifdef NSR_BWD_TU_GOUT
+// Colour-table-only form of the gradients-out backward: the stylisation stage trains `x_color_embedder` alone (trainers/style.py:25),
+// so no weight gradient is wanted (grad_mlp == NULL) and nothing behind the density output either.  What is left of the chain is
+// the forward recompute of the class and colour nets (for the ReLU masks) and their input gradients -- 60 of the full kernel's
+// ~190 MFMAs, none of its 240 accumulators, so the kernel runs at two waves per SIMD (LDS: the 60 KB weight image) instead of one
+// (1008x756 stylisation iteration, 24 patches on four streams: 41.1 -> 39.4 ms).  Same helper calls in the same order as the full kernel: the
+// colour gradients are bit-identical to its.  gout's density components are written as zeros (the scatter ignores them).
+template <int CD>
+__global__ void __launch_bounds__(BWD_THREADS)
+k_field_bwd_color(FieldBwdArgs b) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    short *wl = reinterpret_cast<short *>(smem);
+    short *wt = wl + FW_TOTAL;
+    const FieldArgs &a = b.f;
+    field_build_fw<CD, false>(wl, a.params);
+    field_build_bw<CD>(wt, a.params);
+    __syncthreads();
+    const uint32_t Mc = a.m_dev ? min((uint32_t)max(a.m_dev[0], 0), a.M) : a.M;
+    const uint32_t ntiles = (Mc + 15) / 16;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int s = lane & 15, g = lane >> 4;
+    const uint32_t lb = field_logical_block();
+    const uint32_t tpb = (ntiles + gridDim.x - 1) / gridDim.x;
+    const uint32_t t_begin = lb * tpb;
+    const uint32_t t_end = min(t_begin + tpb, ntiles);
+    for (uint32_t tile = t_begin + wave; tile < t_end; tile += BWD_THREADS / 64) {
+        const uint32_t mpos = tile * 16 + s;
+        const bool valid = mpos < Mc;
+        const uint32_t m = a.perm[min(mpos, Mc - 1u)];
+        const float u0 = field_unit(a.xyzs[(size_t)m * 3 + 0], a.bmin[0], a.bsize[0]);
+        const float u1 = field_unit(a.xyzs[(size_t)m * 3 + 1], a.bmin[1], a.bsize[1]);
+        const float u2 = field_unit(a.xyzs[(size_t)m * 3 + 2], a.bmin[2], a.bsize[2]);
+        const bool live = valid && (u0 >= 0 && u0 <= 1 && u1 >= 0 && u1 <= 1 && u2 >= 0 && u2 <= 1);
+        float grgb[4];
+        {
+            const float *gp = b.grad_rgbs + (size_t)m * a.C_ch;
+            if (a.C_ch == 8) {
+                const float4 t4 = reinterpret_cast<const float4 *>(gp)[g & 1];
+                grgb[0] = t4.x; grgb[1] = t4.y; grgb[2] = t4.z; grgb[3] = t4.w;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; e++) grgb[e] = gp[(uint32_t)(4 * g + e) < a.C_ch ? 4 * g + e : 0];
+            }
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+                if (!(valid && (a.C_ch == 8 ? g < 2 : (uint32_t)(4 * g + e) < a.C_ch))) grgb[e] = 0.f;
+        }
+        const s8v xc[1] = {(reinterpret_cast<const s8v *>(a.feats) + ((size_t)tile * 64 + lane) * 2)[1]};
+        // ---- forward recompute (rounded activations) ----
+        f4v h[4];
+        s8v hk[2], hc[2], hr1[2], hr2[2];
+        f4v c1[1], rgb[1];
+        mm_layer32<CD, 4, 1>(wl + FW_K1, lane, xc, h);
+        mm_pack64<CD, true, NSR_BWD_PKMAX>(h, hk);
+        mm_layer32<CD, 4, 1>(wl + FW_C1A, lane, xc, h);
+        mm_pack64<CD, true, NSR_BWD_PKMAX>(h, hc);
+        mm_layer32<CD, 1, 2>(wl + FW_C1B, lane, hc, c1);
+        const s4v c1b = mm_round4<CD, false>(c1[0]);
+        mm_layer16<CD, 4>(wl + FW_R1, lane, c1b, h);
+        mm_pack64<CD, true, NSR_BWD_PKMAX>(h, hr1);
+        mm_layer32<CD, 4, 2>(wl + FW_R2, lane, hr1, h);
+        mm_pack64<CD, true, NSR_BWD_PKMAX>(h, hr2);
+        mm_layer32<CD, 1, 2>(wl + FW_R3, lane, hr2, rgb);
+        // ---- upstream gradients in B-fragment form (row = 4g + e) ----
+        s4v dyr, dyk;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const int ch = 4 * g + e;
+            float gr = 0.f, gk = 0.f;
+            if (valid && (uint32_t)ch < a.C_ch) {
+                if (ch < 3) {
+                    const float sg = field_sigmoid(rgb[0][e]);
+                    gr = grgb[e] * sg * (1.0f - sg);
+                } else {
+                    gk = grgb[e];
+                }
+            }
+            dyr[e] = MM<CD>::cvt(gr);
+            dyk[e] = MM<CD>::cvt(gk);
+        }
+        // ---- colour-2, colour-1, class: input gradients ----
+        s8v g2[2], g1[2], gh[2];
+        f4v t1[1], gxc[2];
+        mm_layer16<CD, 4>(wt + BW_R3T, lane, dyr, h);
+        field_mask_pack<CD>(h, hr2, g2);
+        mm_layer32<CD, 4, 2>(wt + BW_R2T, lane, g2, h);
+        field_mask_pack<CD>(h, hr1, g1);
+        mm_layer32<CD, 1, 2>(wt + BW_R1T, lane, g1, t1);
+        const s4v gc1 = mm_round4<CD, false>(t1[0]);
+        mm_layer16<CD, 4>(wt + BW_C1BT, lane, gc1, h);
+        field_mask_pack<CD>(h, hc, gh);
+        mm_layer32<CD, 2, 2>(wt + BW_C1AT, lane, gh, gxc);
+        mm_layer16<CD, 4>(wt + BW_K2T, lane, dyk, h);
+        field_mask_pack<CD>(h, hk, gh);
+        mm_layer32_acc<CD, 2, 2>(wt + BW_K1T, lane, gh, gxc);
+        if (valid) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int t = i >> 1, e0 = 2 * (i & 1);
+                const int lv_i = (i < 2 ? 2 * g : 8 + 2 * g) + (i & 1);
+                b.gout[(size_t)m * 16 + lv_i] = live ? make_float4(0.f, 0.f, gxc[t][e0], gxc[t][e0 + 1]) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    }
+}
+template <int CD>
+static int field_bwd_launch_color(const FieldBwdArgs &b, hipStream_t s) {
+    const size_t lds = (size_t)(FW_TOTAL + BW_TOTAL) * 2;
+    static bool attr_set[64] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (!attr_set[dev & 63]) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_field_bwd_color<CD>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds) != hipSuccess)
+            return NSR_ERR_LAUNCH;
+        attr_set[dev & 63] = true;
+    }
+    // two resident workgroups per CU; >= 8 tiles per wave so that the weight-image build amortises
+    const uint32_t ntiles = (b.f.M + 15) / 16;
+    uint32_t nb = (ntiles + 31) / 32;
+    if (nb > 512) nb = 512;
+    if (nb == 0) nb = 1;
+    hipLaunchKernelGGL((k_field_bwd_color<CD>), dim3(nb), dim3(BWD_THREADS), lds, s, b);
+    return nsr_launch_status();
+}
+
 int nsr_field_bwd_launch_gout(const FieldBwdArgs &b, int table_dtype, int compute_dtype, bool feats, dim3 grid, hipStream_t s) {
 #if !NSR_BWD_EARLY_NEXT
     if (b.f.perm != nullptr) return NSR_ERR_UNSUPPORTED;      // an ablation build without the index prefetch cannot walk a permutation
 #endif
+    static const int color_env = [] { const char *e = getenv("NSR_BWD_COLOR_ONLY"); return e ? atoi(e) : 1; }();
+    if (color_env && b.grad_mlp == nullptr && !b.train_density && b.train_color && feats && b.f.perm != nullptr) {
+        if (compute_dtype == NSR_F16) return field_bwd_launch_color<NSR_F16>(b, s);
+        if (compute_dtype == NSR_BF16) return field_bwd_launch_color<NSR_BF16>(b, s);
+    }
     return field_bwd_launch_variant<true>(b, table_dtype, compute_dtype, feats, grid, s);
 }
 #else

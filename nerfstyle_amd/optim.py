@@ -40,6 +40,7 @@ class FusedAdam:
         model._ensure_grad()
         model.train_density_table = bool(self.table_mask & 0x3)
         model.train_color_table = bool(self.table_mask & 0xC)
+        model.train_mlps = bool(self.nets)
         # torch.optim-like surface for LR schedulers
         self.param_groups = [{'lr': lr, 'initial_lr': lr, 'params': [model.arena]}]
 

@@ -136,7 +136,7 @@ class _field(Function):
             def call(perm, wsp):
                 return L.lib().nsr_field_backward(
                     ctypes.byref(desc), L.p(tables), L.p(model._mlp_flat()), L.p(xyzs), M, L.p(ctx.m_dev),
-                    L.p(grad_sigmas), L.p(grad_rgbs), L.p(ga), ga.data_ptr() + model.table_elems * 4,
+                    L.p(grad_sigmas), L.p(grad_rgbs), L.p(ga), (ga.data_ptr() + model.table_elems * 4) if model.train_mlps else None,
                     int(model.train_density_table), int(model.train_color_table), L.p(feats), L.p(perm), L.p(wsp),
                     L.stream())
             st = call(perm, ws)
@@ -203,6 +203,7 @@ class StyleTCNerf(nn.Module):
         self.table_dtype = torch.float16 if enc_dtype in (None, torch.float16) else torch.float32
         self.train_density_table = True
         self.train_color_table = True
+        self.train_mlps = True                   # False (set by an optimiser that trains no net): the backward skips the weight gradients
         self.save_features = True     # forward keeps 128 B/sample of encoded features for the backward
 
         max_bound = torch.max(bbox.size).item()

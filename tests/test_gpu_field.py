@@ -397,6 +397,17 @@ def test_sample_order_and_sorted_walk_equal_buffer_order(O, dev, dt, table_dtype
     _, _, g3 = run(perm, density=False)
     t3, t0 = g3[:m.table_elems].view(m.rows, 2, 2), g0[:m.table_elems].view(m.rows, 2, 2)
     assert float(t3[:, 0].abs().max()) == 0.0 and rel_l2(t3[:, 1].cpu().numpy(), t0[:, 1].cpu().numpy()) < 2e-5
+    # ... and no net trained either (the stylisation stage, trainers/style.py:25): the colour-only gradients-out kernel
+    # (k_field_bwd_color: class + colour nets' input gradients, no weight gradients, nothing behind sigma)
+    m.train_mlps = False
+    try:
+        _, _, g4 = run(perm, density=False)
+    finally:
+        m.train_mlps = True
+    t4 = g4[:m.table_elems].view(m.rows, 2, 2)
+    assert float(t4[:, 0].abs().max()) == 0.0 and float(g4[m.table_elems:].abs().max()) == 0.0
+    assert rel_l2(t4[:, 1].cpu().numpy(), t3[:, 1].cpu().numpy()) < 2e-6         # the same arithmetic; atomics order only
+    assert rel_l2(t4[:, 1].cpu().numpy(), t0[:, 1].cpu().numpy()) < 2e-5
     # sigma-only forward through the permutation
     with torch.no_grad():
         s_only = m.field(xyzs, True, counter, perm=perm)
