@@ -350,8 +350,11 @@ def run_recon(args, dev, rank, world):
         from nerfstyle_amd.graph import GraphedRenderStep
         # one process: the optimiser step (device-side scaler, lr schedule, EMA decay) is part of the captured step
         in_graph_opt = world == 1 and scaler is not None
+        # ... and the next step's ray generation + march run beside it (GraphedRenderStep(prefetch=True)); batches that fill the
+        # chip with their march gain nothing from it
+        graph_prefetch = in_graph_opt and n_rays <= 65536 and os.environ.get('NSR_BENCH_GRAPH_PREFETCH', '1') != '0'
         graphed = GraphedRenderStep(r, n_rays, loss_fn, optimizer=opt if in_graph_opt else None,
-                                    scaler=scaler if in_graph_opt else None, lr_decay_steps=30000)
+                                    scaler=scaler if in_graph_opt else None, lr_decay_steps=30000, prefetch=graph_prefetch)
 
     # Pixels of a step: n_rays distinct pixels, uniformly at random (np.random.choice(..., replace=False), nerf_lib.py:134).
     # Consecutive chunks of ONE random permutation of the frame are exactly such draws, so a permutation (a device sort: 22
@@ -382,15 +385,21 @@ def run_recon(args, dev, rank, world):
     last_it = args.warmup + args.steps - 1
 
     def inputs(it):
+        # (two entries are kept: the captured step with prefetch is told the NEXT step's pose and pixels, and recognises them
+        # by identity when they come back as the current ones)
         if it not in nxt:
-            nxt.clear()
+            for k in [k for k in nxt if k < it - 1]:
+                del nxt[k]
             nxt[it] = (poses[(it * 7 + rank) % poses.shape[0]], draw_pixels())
         return nxt[it]
 
     def step(it):
         pose, pix = inputs(it)
         if graphed is not None:
-            loss = graphed(pose, pix)
+            if graphed.prefetch:
+                loss = graphed(pose, pix, *inputs(it + 1))
+            else:
+                loss = graphed(pose, pix)
             cnt = r._last_counter
         else:
             ctx = pending.pop(it, None)
@@ -541,7 +550,9 @@ def run_recon(args, dev, rank, world):
     if sp_lambda > 0:
         wl += ', --sparsity_lambda {} (50 000 sigma-only points per step, with gradient)'.format(sp_lambda)
     if args.graph:
-        wl += ', render+loss+backward{} replayed as one hipGraph'.format('+optimiser' if graphed.optimizer is not None else '')
+        wl += ', render+loss+backward{} replayed as one hipGraph{}'.format(
+            '+optimiser' if graphed.optimizer is not None else '',
+            " (the next step's ray generation + march on a second branch beside the optimiser)" if graphed.prefetch else '')
     return {
         'metric': 'train Mrays/sec', 'value': round(value, 4), 'unit': 'Mrays/s', 'n_gpus': world, 'steps': args.steps,
         'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True,

@@ -23,7 +23,8 @@ class GraphedRenderStep:
     Gradients accumulate into model.arena.grad exactly as in eager mode."""
 
     def __init__(self, renderer: Renderer, n_rays: int, loss_fn: Callable[[Dict[str, torch.Tensor], torch.Tensor], torch.Tensor],
-                 warmup: int = 2, dense: bool = False, optimizer=None, scaler=None, lr_decay_steps: float = 0.0):
+                 warmup: int = 2, dense: bool = False, optimizer=None, scaler=None, lr_decay_steps: float = 0.0,
+                 prefetch: bool = False):
         # optimizer (FusedAdam) + scaler (LossScaler): the optimiser step joins the graph.  Possible since round 3: learning rate,
         # step count, bias corrections, loss scale, skip decision and the EMA decay are device-side scalars (nsr_scaler_update),
         # so nothing the captured kernels need changes on the host from step to step.  Without them the caller steps the
@@ -46,6 +47,42 @@ class GraphedRenderStep:
         self.graph = None
         self.loss = None
         self._warmup = warmup
+        # prefetch: the captured step is  shade + loss + backward of THIS step's samples  ->  { optimiser step  ||  ray generation +
+        # march + compaction (+ sample order) of the NEXT step's pixels }.  The march reads the occupancy bitfield only, never the
+        # parameters, so it may run beside the optimiser: at 4 096 rays the ~0.15 ms of latency-bound march kernels disappear
+        # under the ~0.21 ms of the HBM-bound inf/nan check + Adam pass.  The marched samples live in static buffers (`_stage`)
+        # that the next replay's shade reads; graph(pose, pix, pose_next, pix_next) -- a call whose (pose, pix) are not the
+        # objects announced by the previous call, or that follows an occupancy update, marches eagerly first.
+        self.prefetch = bool(prefetch)
+        self.pose_next = self.pose.clone()
+        self.pix_next = self.pix.clone()
+        self._stage = None               # ctx of Renderer.begin_train whose tensors are the static sample buffers
+        self._announced = (None, None)
+
+    def _restage(self, pose, pix):
+        """march (pose, pix) now, on the current stream, into the static sample buffers (allocated by the first call)"""
+        keep = self.r.update_occ
+        self.r.update_occ = False          # no occupancy update and no step bookkeeping in here: __call__ keeps the schedule
+        try:
+            self._stage = self.r.begin_train(pose, pix, dense=self.dense, into=self._stage)
+        finally:
+            self.r.update_occ = keep
+
+    def _body_prefetch(self, with_optimizer=True):
+        out = self.r.finish_train(self._stage)
+        loss = self.loss_fn(out, self.pix)
+        if loss.requires_grad:
+            loss.backward()
+        main = torch.cuda.current_stream(self.r.device)
+        side = self._side
+        side.wait_stream(main)                                   # fork: the backward no longer needs the staged samples
+        with torch.cuda.stream(side):
+            self._restage(self.pose_next, self.pix_next)
+            self.pix.copy_(self.pix_next)                        # the loss of the NEXT replay gathers its targets with these
+        if with_optimizer and self.optimizer is not None:
+            self.optimizer.step(scaler=self.scaler, lr_decay_steps=self.lr_decay_steps)
+        main.wait_stream(side)                                   # join
+        return loss.detach()
 
     def _body(self, with_optimizer=True):
         keep = self.r.update_occ
@@ -61,9 +98,12 @@ class GraphedRenderStep:
             self.optimizer.step(scaler=self.scaler, lr_decay_steps=self.lr_decay_steps)
         return loss.detach()
 
-    def capture(self, pose: torch.Tensor, pix: torch.Tensor):
+    def capture(self, pose: torch.Tensor, pix: torch.Tensor, pose_next=None, pix_next=None):
         self.pose.copy_(pose)
         self.pix.copy_(pix)
+        if self.prefetch:
+            self.pose_next.copy_(pose_next if pose_next is not None else pose)
+            self.pix_next.copy_(pix_next if pix_next is not None else pix)
         model = self.r.model
         model._ensure_grad()
         # the f16 gather copy must be current BEFORE capture: a captured replay reads the copy the optimiser keeps in sync
@@ -84,28 +124,49 @@ class GraphedRenderStep:
                 self._body(with_optimizer=False)   # warm-up renders only: no parameter update, no step counted
         torch.cuda.current_stream().wait_stream(s)
         model.arena.grad.zero_()           # the warm-up passes accumulated gradients
+        if self.prefetch:
+            self._side = torch.cuda.Stream(device=self.r.device)
+            self._restage(self.pose, self.pix)             # this step's samples: eager, into what become the static buffers
+            torch.cuda.synchronize(self.r.device)
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
-            self.loss = self._body()
-        self._counter = self.r._last_counter   # the captured march's counter (graph-pool memory, refilled by every replay)
+            self.loss = self._body_prefetch() if self.prefetch else self._body()
+        self._counter = self._stage['mt']['counter'] if self.prefetch else self.r._last_counter   # the captured march's counter (refilled by every replay)
         model.arena.grad.zero_()           # capture does not execute, but keep the contract explicit
         return self
 
-    def __call__(self, pose: torch.Tensor, pix: torch.Tensor) -> torch.Tensor:
-        if self.graph is None:
-            self.capture(pose, pix)
+    def __call__(self, pose: torch.Tensor, pix: torch.Tensor, pose_next=None, pix_next=None) -> torch.Tensor:
+        first = self.graph is None
+        if first:
+            self.capture(pose, pix, pose_next, pix_next)
         r = self.r
+        updated = False
         if self.occ_updates:
             if r.local_step % r.cfg.update_iter == 0:
                 r.update_state()
+                updated = True
             r.local_step += 1
         m = r.model
         if m.table_dtype == torch.float16 and m._half_version != m.arena._version:
             # parameters changed by something other than FusedAdam (load_state_dict, an EMA swap, a stock optimiser):
             # refresh the f16 gather copy the captured kernels read
             m._gather_tables()
-        self.pose.copy_(pose)
-        self.pix.copy_(pix)
+        if self.prefetch:
+            # the staged samples (and the pixel ids the previous replay left in self.pix) are this step's only if the previous
+            # replay marched exactly these pixels of this pose through the bitfield that is current now (never across an
+            # occupancy update, like the data-parallel overlap); otherwise: march now
+            if first or updated or self._announced[0] is not pose or self._announced[1] is not pix:
+                self.pose.copy_(pose)
+                self.pix.copy_(pix)
+                self._restage(self.pose, self.pix)
+            if pose_next is None:
+                pose_next, pix_next = pose, pix
+            self.pose_next.copy_(pose_next)
+            self.pix_next.copy_(pix_next)
+            self._announced = (pose_next, pix_next)
+        else:
+            self.pose.copy_(pose)
+            self.pix.copy_(pix)
         self.graph.replay()
         self.r._last_counter = self._counter
         return self.loss

@@ -39,6 +39,17 @@ class _near_far_from_aabb(Function):
 near_far_from_aabb = _near_far_from_aabb.apply
 
 
+def near_far_from_aabb_into(rays_o, rays_d, aabb, min_near, nears, fars):
+    """near_far_from_aabb writing into caller-owned [N] float32 buffers (static buffers of a captured step)"""
+    rays_o = _f32(rays_o).view(-1, 3)
+    rays_d = _f32(rays_d).view(-1, 3)
+    N = rays_o.shape[0]
+    assert nears.numel() == N and fars.numel() == N and nears.dtype == fars.dtype == torch.float32
+    L.check(L.lib().nsr_near_far_from_aabb(L.p(rays_o), L.p(rays_d), L.p(_f32(aabb)), N, float(min_near), L.p(nears),
+                                           L.p(fars), L.stream()), 'near_far_from_aabb')
+    return nears, fars
+
+
 def morton3D(coords):
     """raymarching.py:89-113: coords [N,3] int -> indices [N] int32"""
     coords = coords.int().contiguous()
@@ -74,7 +85,7 @@ def _march_workspace(N, device, bound, max_steps):
 
 
 def march_rays_train_nosync(rays_o, rays_d, bound, density_bitfield, C, H, nears, fars, M, step_counter,
-                            dt_gamma=0., max_steps=1024, want_dirs=False):
+                            dt_gamma=0., max_steps=1024, want_dirs=False, out=None):
     """Capacity-bounded march: emits into [M, .] buffers and never reads the sample count on the
     host (the count stays in step_counter[0] on the device).  Samples past the count are NOT
     zero-filled (the reference memsets 40 B x N x max_steps per call, raymarching.py:238-240):
@@ -84,10 +95,16 @@ def march_rays_train_nosync(rays_o, rays_d, bound, density_bitfield, C, H, nears
     rays_d = _f32(rays_d).view(-1, 3)
     N = rays_o.shape[0]
     dev = rays_o.device
-    xyzs = torch.empty(M, 3, dtype=torch.float32, device=dev)
-    dirs = torch.empty(M, 3, dtype=torch.float32, device=dev) if want_dirs else None
-    deltas = torch.empty(M, 4, dtype=torch.float32, device=dev)
-    rays = torch.empty(N, 3, dtype=torch.int32, device=dev)
+    if out is not None:
+        # caller-owned sample buffers (xyzs [M,3], deltas [M,4] f32, rays [N,3] i32), e.g. the static buffers of a captured step
+        xyzs, deltas, rays = out
+        assert xyzs.shape == (M, 3) and deltas.shape == (M, 4) and rays.shape == (N, 3) and not want_dirs
+        dirs = None
+    else:
+        xyzs = torch.empty(M, 3, dtype=torch.float32, device=dev)
+        dirs = torch.empty(M, 3, dtype=torch.float32, device=dev) if want_dirs else None
+        deltas = torch.empty(M, 4, dtype=torch.float32, device=dev)
+        rays = torch.empty(N, 3, dtype=torch.int32, device=dev)
     ws = _march_workspace(N, dev, bound, max_steps)
     with profiling.timed('march_train'):
         L.check(L.lib().nsr_march_rays_train(

@@ -207,8 +207,22 @@ class Renderer(torch.nn.Module):
             perm = self.model.sample_order(mt['xyzs'], mt['counter'])
         return self.shade_train(mt, perm)
 
-    def march_train(self, rays: RayBatch) -> dict:
-        """near/far + occupancy-grid march + compaction: capacity-sized sample buffers, device-side counts."""
+    def march_train(self, rays: RayBatch, into: Optional[dict] = None) -> dict:
+        """near/far + occupancy-grid march + compaction: capacity-sized sample buffers, device-side counts.
+        into: the dict a previous call returned -- its tensors are written in place (static buffers of a captured step)."""
+        if into is not None:
+            nears, fars = raymarching.near_far_from_aabb_into(rays.origins, rays.dirs, self.aabb, self.cfg.min_near,
+                                                              into['nears'], into['fars'])
+            counter = into['counter']
+            counter.zero_()
+            self._last_counter = counter
+            N, M = into['N'], into['M']
+            assert rays.origins.shape[0] == N
+            self._last_capacity = M
+            raymarching.march_rays_train_nosync(
+                rays.origins, rays.dirs, self.bound, self.march_bitfield, self.cascade, self.cfg.grid_size, nears, fars,
+                M, counter, 0., self.cfg.max_steps, out=(into['xyzs'], into['deltas'], into['rays_info']))
+            return into
         nears, fars = raymarching.near_far_from_aabb(rays.origins, rays.dirs, self.aabb, self.cfg.min_near)
         if self.update_occ:
             counter = self.step_counter[self.local_step % STEP_CTR_SIZE]
@@ -327,7 +341,7 @@ class Renderer(torch.nn.Module):
         """The next training render starts with update_state (renderer.py:206-207): it reads the parameters."""
         return bool(self.update_occ and (self.local_step % self.cfg.update_iter == 0))
 
-    def begin_train(self, pose, pix_subset, dense: bool = False) -> dict:
+    def begin_train(self, pose, pix_subset, dense: bool = False, into: Optional[dict] = None) -> dict:
         """First half of render(pose, training=True, pix_subset=...): ray generation, [occupancy update when due,] occupancy
         march + compaction and the spatial order of the samples.  Apart from the occupancy update none of it reads the
         PARAMETERS (the march reads the bitfield only), so a data-parallel step may issue it for step i+1 while the gradient
@@ -336,10 +350,14 @@ class Renderer(torch.nn.Module):
         rays, _ = generate_rays(pose, self.intr, None, camera_flip=self.cfg.flip_camera, pix_subset=pix_subset, device=self.device)
         if self.occupancy_update_due():
             self.update_state()
-        mt = self.march_train(rays)
+        # into: the ctx a previous call returned; every tensor of it is rewritten in place (graph.GraphedRenderStep(prefetch=True))
+        mt = self.march_train(rays, into=into['mt'] if into is not None else None)
         perm = None
         if torch.is_grad_enabled() and self._use_spatial_order(mt['N'], dense):
-            perm = self.model.sample_order(mt['xyzs'], mt['counter'])
+            perm = self.model.sample_order(mt['xyzs'], mt['counter'], out=into['perm'] if into is not None else None)
+        if into is not None:
+            assert (perm is None) == (into['perm'] is None)
+            return into
         return {'mt': mt, 'perm': perm}
 
     def finish_train(self, ctx: dict) -> Dict[str, torch.Tensor]:

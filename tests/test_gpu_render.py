@@ -918,10 +918,16 @@ def test_graph_with_optimiser_inside_equals_eager_steps(O, dev):
 
         def loss_fn(o, p):
             return recon_loss(o['rgb_map'], o['classes'], cur['t'], t_cls, p, scale=sc.scale_tensor(dev))
-        step = GraphedRenderStep(r, pix.numel(), loss_fn, dense=True, optimizer=opt, scaler=sc, lr_decay_steps=50.0) if graphed else None
+        step = GraphedRenderStep(r, pix.numel(), loss_fn, dense=True, optimizer=opt, scaler=sc, lr_decay_steps=50.0,
+                                 prefetch=graphed == 'prefetch') if graphed else None
+        P = [pose_t[i] for i in range(6)]
         for it in range(5):
             cur['t'].copy_(targets[it])                                    # a static buffer: replays read the new contents
-            if graphed:
+            if graphed == 'prefetch':
+                # the next step's pose and pixels are announced; step 3 arrives as a DIFFERENT tensor object than announced
+                # (same values): the staged samples are not trusted, the step marches eagerly first
+                step(P[it] if it != 3 else pose_t[3], pix, P[it + 1], pix)
+            elif graphed:
                 step(pose_t[it], pix)
             else:
                 out = r.render(pose_t[it], None, training=True, pix_subset=pix, dense=True)
@@ -935,6 +941,10 @@ def test_graph_with_optimiser_inside_equals_eager_steps(O, dev):
     d = (a_g - a_e).abs()
     assert float((d > 1e-5).float().mean()) < 2e-3                          # fp32 atomics order: a few near-zero gradients flip sign
     assert float((ema_g - ema_e).abs().max()) < 0.05 and float((ema_g - a_g).abs().max()) > 1e-4
+    # prefetch: the next step's ray generation + march + sample order on a second branch of the graph, beside the optimiser
+    a_p, ema_p, sc_p, steps_p, n_p = run('prefetch')
+    assert sc_p == sc_e and steps_p == 4 and n_p == 5
+    assert float(((a_p - a_e).abs() > 1e-5).float().mean()) < 2e-3 and float((ema_p - ema_e).abs().max()) < 0.05
 
 
 def test_graphed_patch_backward_equals_eager(O, dev):
