@@ -71,6 +71,9 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--psnr-rays', type=int, default=4096, help='rays of the PSNR-vs-oracle check after the timed region (0: skip)')
     ap.add_argument('--no-loss-scaler', action='store_true', help='constant loss scale, no inf/nan check (round 2 behaviour)')
+    ap.add_argument('--side-march', action='store_true',
+                    help="N == 1, eager steps: ray generation + march + compaction + sample sort of step i+1 on a side stream beside "
+                         "the backward of step i (Renderer.begin_train_on): 34.9 -> 33.5 ms per full-frame step")
     ap.add_argument('--graph', action='store_true',
                     help='replay the render+loss+backward part of the step as one captured hipGraph (small-batch series)')
     ap.add_argument('--cpu-budget-s', type=float, default=12.0)
@@ -379,10 +382,15 @@ def run_recon(args, dev, rank, world):
         return perm_state['perm'][p0:p0 + n_rays]
 
     # N > 1: the parameter-independent front of step i+1 (ray generation, march, compaction, sample sort: Renderer.begin_train)
-    # is issued while the gradient all-reduce of step i is in flight (parallel.sync_gradients_async); N == 1: no overlap, no
-    # side stream, steps run back to back
+    # is issued while the gradient all-reduce of step i is in flight (parallel.sync_gradients_async)
     nxt, pending = {}, {}
+    # N == 1, eager steps: the parameter-independent front of step i+1 runs on a side stream beside the backward of step i
+    # (--side-march; off by default: the backward pair's HIP-event time -- the roofline figure of this line -- then includes the
+    # march and sort kernels that run beside it, 23.5 instead of 21.8 ms, while the step drops from 34.9 to 33.5 ms)
+    side_on = args.side_march or os.environ.get('NSR_BENCH_SIDE_MARCH', '0') == '1'
+    side_stream = torch.cuda.Stream(device=dev) if (world == 1 and not args.graph and side_on) else None
     last_it = args.warmup + args.steps - 1
+    stage = [None, None]
 
     def inputs(it):
         # (two entries are kept: the captured step with prefetch is told the NEXT step's pose and pixels, and recognises them
@@ -402,14 +410,31 @@ def run_recon(args, dev, rank, world):
                 loss = graphed(pose, pix)
             cnt = r._last_counter
         else:
+            ev_next = None
+            if side_stream is not None and it < last_it:
+                inputs(it + 1)                 # (drawn now: whatever produces them is enqueued ahead of this step's kernels)
             ctx = pending.pop(it, None)
             if ctx is None:
                 ctx = r.begin_train(pose, pix)
             out = r.finish_train(ctx)
+            if side_stream is not None:
+                # the side stream's march starts when this step's forward is done: beside the BACKWARD (the table scatter waits on
+                # the atomic unit with idle issue slots; beside the forward the march's bitfield loads fight the hash gather for
+                # the L1).  Everything the march depends on -- its inputs, the last occupancy update -- is older than this event
+                ev_next = torch.cuda.Event()
+                ev_next.record()
             cnt = r._last_counter           # this render's device-side sample count
             loss = loss_fn(out, pix)
             if loss.requires_grad:         # the sparsity term; the reconstruction loss has back-propagated itself
                 loss.backward()
+            if side_stream is not None and it < last_it and not r.occupancy_update_due():
+                # the next step's ray generation + march + compaction + sample sort, on the side stream, beside this step's
+                # backward (Renderer.begin_train_on)
+                # two sets of sample buffers, rewritten in place in turn: set k is read by step i (forward + backward) while the
+                # side stream fills the other one, and is refilled only after a later forward's event, i.e. after that backward
+                slot = (it + 1) % 2
+                stage[slot] = r.begin_train_on(side_stream, *inputs(it + 1), after=ev_next, into=stage[slot])
+                pending[it + 1] = stage[slot]
         if world > 1:
             sync = P.sync_gradients_async(model, optimizer=opt)
             if graphed is None and it < last_it and not r.occupancy_update_due():
@@ -562,6 +587,10 @@ def run_recon(args, dev, rank, world):
             'num_classes': nc, 'table_dtype': args.table_dtype, 'mfma_dtype': args.compute_dtype,
             'params': int(model.arena.numel()), 'parallelism': 'rays sharded x{} + RCCL all-reduce'.format(world) + (
                 " (async, overlapped with the next step's march + sample sort)" if world > 1 and graphed is None else ''),
+            'next_step_front': ('ray generation + march + compaction + sample sort of step i+1 on a side stream beside the backward of '
+                                'step i (Renderer.begin_train_on; never across an occupancy update)' if side_stream is not None else
+                                ('second branch of the captured step, beside the optimiser' if (graphed is not None and graphed.prefetch)
+                                 else 'in line')),
             'pixel_order': ('every pixel of the frame once per step, visited in 8x8 tiles (a full draw without replacement: order-free)'
                             if tile_order is not None else 'uniform draws without replacement (chunks of one device randperm of the frame)'),
             'occupancy_updates_in_timed_region': occ_updates,

@@ -222,6 +222,10 @@ class Renderer(torch.nn.Module):
             raymarching.march_rays_train_nosync(
                 rays.origins, rays.dirs, self.bound, self.march_bitfield, self.cascade, self.cfg.grid_size, nears, fars,
                 M, counter, 0., self.cfg.max_steps, out=(into['xyzs'], into['deltas'], into['rays_info']))
+            if self.update_occ:
+                # the step bookkeeping of the allocating path: the count ring behind mean_count, the occupancy schedule's step
+                self.step_counter[self.local_step % STEP_CTR_SIZE].copy_(counter)
+                self.local_step += 1
             return into
         nears, fars = raymarching.near_far_from_aabb(rays.origins, rays.dirs, self.aabb, self.cfg.min_near)
         if self.update_occ:
@@ -360,8 +364,33 @@ class Renderer(torch.nn.Module):
             return into
         return {'mt': mt, 'perm': perm}
 
+    def begin_train_on(self, stream, pose, pix_subset, dense: bool = False, after=None, into: Optional[dict] = None) -> dict:
+        """begin_train issued on `stream` (a side stream) so that it runs BESIDE whatever the current stream is doing -- the
+        previous step's backward: its table scatter waits on the memory-side atomic unit with most of its issue slots idle, and
+        the march / sort kernels fit next to it.  finish_train(ctx) makes the current stream wait for it.  Only legal when no
+        occupancy update is due (occupancy_update_due(): that one reads the parameters).  after: an event the side stream waits
+        for first (the producer of `pose` / `pix_subset`, the last occupancy update, the last reader of `into`).
+        into: the ctx of an earlier call whose tensors are rewritten in place -- a training loop alternates between two of them
+        and allocates nothing per step.  Without it the tensors are allocated by the side stream and consumed -- and released
+        -- by the current one: they are marked for the caching allocator accordingly (which then keeps two pools of
+        capacity-sized buffers busy; prefer `into`)."""
+        assert not self.occupancy_update_due(), 'an occupancy update reads the parameters: march on the training stream'
+        cur = torch.cuda.current_stream(self.device)
+        if after is not None:
+            stream.wait_event(after)
+        with torch.cuda.stream(stream):
+            ctx = self.begin_train(pose, pix_subset, dense, into=into)
+        if into is None:
+            for t in list(ctx['mt'].values()) + [ctx['perm']]:
+                if torch.is_tensor(t):
+                    t.record_stream(cur)
+        ctx['stream'] = stream
+        return ctx
+
     def finish_train(self, ctx: dict) -> Dict[str, torch.Tensor]:
         """Second half: fused field + composite + epilogue on the samples begin_train marched (reads the parameters)."""
+        if ctx.get('stream') is not None:
+            torch.cuda.current_stream(self.device).wait_stream(ctx['stream'])
         out = {'target': None}
         out['rgb_map'], out['trans_map'], out['classes'] = self.shade_train(ctx['mt'], ctx['perm'])
         self._last_counter, self._last_capacity = ctx['mt']['counter'], ctx['mt']['M']

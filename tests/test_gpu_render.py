@@ -1048,3 +1048,30 @@ def test_sorts_on_two_streams_do_not_disturb_each_other(O, dev):
     torch.cuda.synchronize()
     assert torch.equal(out_a.detach(), ref_a) and torch.equal(out_b.detach(), ref_b)
 
+
+def test_begin_train_on_a_side_stream_equals_plain_render(O, dev):
+    """Renderer.begin_train_on (ray generation + march + compaction + sample order on a side stream) + finish_train ==
+    render(training=True): bit-identical outputs and sample counts, also while the main stream is busy and with the side
+    stream's buffers recycled over several rounds (they are allocated by one stream and released by another)."""
+    r, ref, poses, intr, bits = _setup(dev, cap=192)
+    r.sort_samples = True
+    side = torch.cuda.Stream(device=dev)
+    g = torch.Generator(device=dev)
+    g.manual_seed(3)
+    busy = torch.rand(4096, 4096, device=dev, generator=g)
+    for it in range(4):
+        pix = torch.randperm(intr.w * intr.h, device=dev, generator=g)[:30000]
+        pose = torch.tensor(poses[it], device=dev)
+        want = r.render(pose, None, training=True, pix_subset=pix)
+        want_cnt = r._last_counter.clone()
+        ev = torch.cuda.Event()
+        ev.record()
+        for _ in range(3):
+            busy = busy @ busy * 1e-3                                         # main-stream work the side stream runs beside
+        ctx = r.begin_train_on(side, pose, pix, after=ev)
+        out = r.finish_train(ctx)
+        for k in ('rgb_map', 'trans_map', 'classes'):
+            assert torch.equal(out[k], want[k]), (it, k)
+        assert torch.equal(r._last_counter, want_cnt)
+        out['rgb_map'].sum().backward()                                      # the backward walks the side stream's permutation
+        del ctx, out, want
