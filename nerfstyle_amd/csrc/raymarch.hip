@@ -348,7 +348,7 @@ k_march_emit_mask(const float *__restrict__ rays_o, const float *__restrict__ ra
                   uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M, const float *__restrict__ nears,
                   const float *__restrict__ noises, const uint32_t *__restrict__ counts, const uint32_t *__restrict__ block_bases,
                   const uint32_t *__restrict__ mask, float *__restrict__ xyzs, float *__restrict__ dirs,
-                  float *__restrict__ deltas, int32_t *__restrict__ rays) {
+                  float *__restrict__ deltas, int32_t *__restrict__ rays, int closed_form) {
     __shared__ uint32_t wave_sums[RM_BLOCK / 64];
     const uint32_t n = blockIdx.x * RM_BLOCK + threadIdx.x;
     const uint32_t num_steps = n < N ? counts[n] : 0u;
@@ -382,6 +382,41 @@ k_march_emit_mask(const float *__restrict__ rays_o, const float *__restrict__ ra
     float last_t = t;
     for (uint32_t w = 0; step < num_steps; w++) {
         uint32_t word = mask[(size_t)w * N + n];
+        // Constant step (dt_gamma = 0) inside one binade: the word's 32 parameters are t, t_1 = t + dt and t_j = bits(t_1) +
+        // (j - 1) (bits(t_2) - bits(t_1)) -- the floats the 32 serial additions give (wpr_block_t has the argument) -- so only the
+        // MARKED steps cost instructions.  Words that cross a binade keep the serial form.
+        bool closed = false;
+        uint32_t b1 = 0, cc = 0;
+        if (closed_form && dt_gamma == 0.0f && t > 0.0f) {
+#pragma clang fp contract(off)
+            const float dt0 = rm_clamp(t * dt_gamma, c.dt_min, c.dt_max);
+            const float t1 = t + dt0, t2 = t1 + dt0;
+            b1 = __float_as_uint(t1);
+            const uint32_t b2 = __float_as_uint(t2);
+            cc = b2 - b1;
+            const uint32_t b32 = b1 + 31u * cc;
+            closed = b2 > b1 && (b1 >> 23) == (b32 >> 23) && cc < (1u << 23);
+        }
+        if (closed) {
+            while (word != 0u && step < num_steps) {
+#pragma clang fp contract(off)
+                const uint32_t k = (uint32_t)__builtin_ctz(word);
+                word &= word - 1u;
+                const float tk = k == 0u ? t : __uint_as_float(b1 + (k - 1u) * cc);
+                const float dt = rm_clamp(tk * dt_gamma, c.dt_min, c.dt_max);
+                const float t_next = tk + dt;
+                pxyz[0] = rm_clamp(r.ox + tk * r.dx, -bound, bound);
+                pxyz[1] = rm_clamp(r.oy + tk * r.dy, -bound, bound);
+                pxyz[2] = rm_clamp(r.oz + tk * r.dz, -bound, bound);
+                if (pdir) { pdir[0] = r.dx; pdir[1] = r.dy; pdir[2] = r.dz; pdir += 3; }
+                reinterpret_cast<float2 *>(pdel)[0] = make_float2(dt, t_next - last_t);
+                last_t = t_next;
+                pxyz += 3; pdel += 4;
+                step++;
+            }
+            t = __uint_as_float(b1 + 31u * cc);                  // t_32: the next word's first parameter
+            continue;
+        }
         for (uint32_t b = 0; b < 32u && step < num_steps; b++, word >>= 1) {
 #pragma clang fp contract(off)
             const float dt = rm_clamp(t * dt_gamma, c.dt_min, c.dt_max);
@@ -1009,9 +1044,20 @@ int nsr_march_rays_train(const float *rays_o, const float *rays_d, const float *
     // the reference's ray slots start at the incoming counter[1]; only 0 is supported without a
     // host read (renderer.py:213-214 zeroes the counter before every call)
     hipLaunchKernelGGL(k_scan_block_sums, dim3(1), dim3(1024), 0, s, block_sums, nblocks, counter, N);
-    if (use_mask)
-        hipLaunchKernelGGL(k_march_emit_mask, dim3(nblocks), dim3(RM_BLOCK), 0, s, rays_o, rays_d, bound, dt_gamma, max_steps, N, C,
-                           H, M, nears, noises, counts, block_sums, mask, xyzs, dirs, deltas, rays);
+    // The replaying emit is bound by its stores: every lane appends 12 + 8 bytes at a time to its own ray's two runs, and with
+    // the ~30 waves per CU its 32 registers allow, more partially written lines are open than the L2 holds.  60 KB of (unused)
+    // dynamic LDS per workgroup keeps two workgroups per CU: 1.12-1.20 -> 0.87-1.09 ms on the bench frame (box to box); the
+    // closed-form step of k_march_emit_mask takes another ~15 us at that occupancy, nothing at full occupancy.
+    static const int emit_lds = [] { const char *e = getenv("NSR_MARCH_EMIT_LDS"); return e ? atoi(e) : 61440; }();
+    static const int closed_env = [] { const char *e = getenv("NSR_MARCH_EMIT_CLOSED"); return e ? atoi(e) : 1; }();
+    if (use_mask) {
+        if (emit_lds > 0) {
+            static bool attr = false;
+            if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_march_emit_mask), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64); attr = true; }
+        }
+        hipLaunchKernelGGL(k_march_emit_mask, dim3(nblocks), dim3(RM_BLOCK), (size_t)emit_lds, s, rays_o, rays_d, bound, dt_gamma, max_steps, N, C,
+                           H, M, nears, noises, counts, block_sums, mask, xyzs, dirs, deltas, rays, closed_env);
+    }
     else
         hipLaunchKernelGGL(k_march_emit, dim3(nblocks), dim3(RM_BLOCK), 0, s, rays_o, rays_d, z_hats, grid, bound, dt_gamma,
                            max_steps, is_ndc, N, C, H, M, nears, fars, noises, counts, block_sums, 0u, xyzs, dirs, deltas, rays);
