@@ -67,7 +67,7 @@ def parse():
                          "run spends all but its first 256 steps in; SURVEY 8d: 'steady state, after occupancy warm-up'); 'warmup' = "
                          "the first 256 steps, full updates (C x H^3 queries)")
     ap.add_argument('--sort-samples', choices=['auto', 'on', 'off'], default='auto',
-                    help="spatially ordered table scatter in the backward (nsr_sample_order): 'auto' = batches of >= 140 000 rays, dense pixel sets from 16 384")
+                    help="spatially ordered table scatter in the backward (nsr_sample_order): 'auto' = batches of >= 90 000 rays, dense pixel sets from 16 384")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--psnr-rays', type=int, default=4096, help='rays of the PSNR-vs-oracle check after the timed region (0: skip)')
     ap.add_argument('--no-loss-scaler', action='store_true', help='constant loss scale, no inf/nan check (round 2 behaviour)')

@@ -44,7 +44,7 @@ class Renderer(torch.nn.Module):
         # dense batches only -- on a full 1008x756 frame the backward drops from 49 to 29 ms (+ 1.8 ms sort); on sparse random
         # batches the blocks hold too few samples (65 536 random rays: 6.2 vs 4.5 ms).  True / False force it.
         self.sort_samples = 'auto'
-        self.sort_min_rays = 140000      # any batch of at least this many rays ...
+        self.sort_min_rays = 90000       # any batch of at least this many rays ...
         self.sort_min_dense_rays = 16384  # ... or a DENSE pixel set (full frame / patch / crop: neighbouring pixels) of this many
         self._pinned_bitfield = None
         self.aabb = torch.tensor([-bound, -bound, -bound, bound, bound, bound], dtype=torch.float32)
