@@ -4,8 +4,10 @@ The training path is free of host synchronisation (march compaction counts stay 
 field kernels split their tiles from the device-side count), so the whole forward and backward can be
 captured once with torch.cuda.CUDAGraph (hipGraph on ROCm) and replayed: one graph launch instead of
 ~40 kernel launches and their host-side bookkeeping.  What it buys is launch overhead, i.e. it matters
-for the reference's 4096-ray steps, not for full-frame steps.  The optimiser step stays outside the
-graph: its learning rate and step count are kernel scalars.
+for the reference's 4096-ray steps, not for full-frame steps.  Given a FusedAdam and a device-side
+LossScaler the optimiser step is part of the graph (learning rate, step count, loss scale and the skip
+decision are device scalars), and with prefetch=True the graph forks after the backward: the optimiser
+on one branch, the next step's ray generation + march on the other.
 
 Reference call stack this replaces: trainers/base.py:367-426 (one `calc_loss` + `backward`)."""
 from typing import Callable, Dict
@@ -17,6 +19,7 @@ from .renderer import Renderer
 
 class GraphedRenderStep:
     """graph = GraphedRenderStep(renderer, n_rays, loss_fn); loss = graph(pose, pix)
+    (prefetch=True: loss = graph(pose, pix, pose_next, pix_next) -- the next call's pose and pixels, the SAME tensor objects)
 
     loss_fn(output_dict, pix) -> scalar loss tensor; it must index any per-pixel targets with the `pix`
     tensor it is given (a static buffer refilled before every replay) and must not synchronise.
