@@ -71,6 +71,10 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--psnr-rays', type=int, default=4096, help='rays of the PSNR-vs-oracle check after the timed region (0: skip)')
     ap.add_argument('--no-loss-scaler', action='store_true', help='constant loss scale, no inf/nan check (round 2 behaviour)')
+    ap.add_argument('--style-backprop', choices=['resident', 'deferred'], default='resident',
+                    help="style stage: 'resident' = ONE render of the frame with autograd, activations kept in HBM, d loss / d rgb "
+                         "back through it (stylize.resident_backprop_step); 'deferred' = the reference's structure: no-grad pass, then "
+                         "24 patch re-renders with autograd (trainers/style.py:162-204) -- same gradient")
     ap.add_argument('--side-march', action='store_true',
                     help="N == 1, eager steps: ray generation + march + compaction + sample sort of step i+1 on a side stream beside "
                          "the backward of step i (Renderer.begin_train_on): 34.9 -> 33.5 ms per full-frame step")
@@ -625,7 +629,7 @@ def run_style(args, dev, rank, world):
     from nerfstyle_amd import profiling
     from nerfstyle_amd.losses import SemanticStyleLoss
     from nerfstyle_amd.optim import FusedAdam, LossScaler
-    from nerfstyle_amd.stylize import StyleCriterion, deferred_backprop_step, patch_list
+    from nerfstyle_amd.stylize import StyleCriterion, deferred_backprop_step, patch_list, resident_backprop_step
     from nerfstyle_amd.vgg import VGG16FeatureExtractor
     if args.max_steps is None:
         args.max_steps = 512                                  # README stylisation command: --max_steps 512
@@ -660,8 +664,12 @@ def run_style(args, dev, rank, world):
 
         def image_loss(rgb, classes):
             return crit(rgb, targets[frame], classes, frame_key=frame, it=it)[0]
-        loss, _ = deferred_backprop_step(r, poses[frame], image_loss, patch_size=200, loss_scale=loss_scale, rank=rank, world=world,
-                                         optimizer=opt, with_classes=True, patch_graphs=patch_graphs)
+        if args.style_backprop == 'resident':
+            loss, _ = resident_backprop_step(r, poses[frame], image_loss, loss_scale=loss_scale, rank=rank, world=world,
+                                             optimizer=opt, with_classes=True)
+        else:
+            loss, _ = deferred_backprop_step(r, poses[frame], image_loss, patch_size=200, loss_scale=loss_scale, rank=rank, world=world,
+                                             optimizer=opt, with_classes=True, patch_graphs=patch_graphs)
         opt.step(scaler=scaler)
         return loss
 
@@ -702,11 +710,18 @@ def run_style(args, dev, rank, world):
         'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True,
         'scaling': 'strong', 'vs_baseline': None, 'dtype': args.compute_dtype, 'data': 'synthetic',
         'config': {
-            'workload': ("LLFF '{}' stylisation stage, {}x{} frame per iteration: 1 full-frame no-grad pass + VGG16-relu3 content / "
-                         "semantic-NNFM loss (PyTorch, {}) + {} {} deferred-backprop patches of 200x200, colour table only, max_steps {}; "
-                         "random seeded VGG weights, style image and segment maps (none exist offline)").format(
-                             args.scene, W, H, 'fp32' if args.fp32_loss else 'autocast ' + args.compute_dtype, n_patches,
-                             'eager' if args.no_patch_graphs else 'graph-replayed ({} streams)'.format(patch_graphs.get('streams', 4)), rcfg.max_steps),
+            'workload': (("LLFF '{}' stylisation stage, {}x{} frame per iteration: 1 full-frame no-grad pass + VGG16-relu3 content / "
+                          "semantic-NNFM loss (PyTorch, {}) + {} {} deferred-backprop patches of 200x200, colour table only, max_steps {}; "
+                          "random seeded VGG weights, style image and segment maps (none exist offline)").format(
+                              args.scene, W, H, 'fp32' if args.fp32_loss else 'autocast ' + args.compute_dtype, n_patches,
+                              'eager' if args.no_patch_graphs else 'graph-replayed ({} streams)'.format(patch_graphs.get('streams', 4)), rcfg.max_steps)
+                         if args.style_backprop == 'deferred' else
+                         ("LLFF '{}' stylisation stage, {}x{} frame per iteration: ONE render of the frame with autograd (activations "
+                          "resident in HBM: the reference's no-grad pass + 24 deferred-backprop patch re-renders compute the same gradient "
+                          "twice over) + VGG16-relu3 content / semantic-NNFM loss (PyTorch, {}) + backward through that render, colour table "
+                          "only, max_steps {}; random seeded VGG weights, style image and segment maps (none exist offline)").format(
+                              args.scene, W, H, 'fp32' if args.fp32_loss else 'autocast ' + args.compute_dtype, rcfg.max_steps)),
+            'style_backprop': args.style_backprop,
             'rays_per_step': W * H, 'patches': n_patches, 'max_steps': rcfg.max_steps, 'num_classes': nc,
             'table_dtype': args.table_dtype, 'mfma_dtype': args.compute_dtype,
             'parallelism': 'patches + pass-1 pixel rows sharded x{}, packed colour-table gradient all-reduce'.format(world),

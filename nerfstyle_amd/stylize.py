@@ -11,6 +11,9 @@ Only `x_color_embedder` is optimised in this stage (StyleTrainer.OPTIM_KEYS, sty
 optimiser with FusedAdam(model, keywords=['x_color_embedder']) -- it also switches the density-table
 scatter off in the fused backward.
 
+resident_backprop_step is the same iteration WITHOUT the deferral (one render with autograd, activations resident in HBM):
+what a 288 GB device should run; deferred_backprop_step keeps the reference's structure.
+
 Multi-GPU: patches are independent units, so pass 2 shards the patch list across ranks and pass 1 shards
 pixel rows (all-gathered, <= 9.1 MB for 1008x756); the colour-table gradient is all-reduced with the
 rest of the arena by parallel.sync_gradients.
@@ -176,6 +179,50 @@ def deferred_backprop_step(renderer, pose, image_loss: Callable, patch_size: int
                 patch_graphs[key](pose_t, pix, g)
     for sd in sides[:nstreams - 1]:
         main.wait_stream(sd)
+    if world > 1:
+        P.sync_gradients(renderer.model, optimizer=optimizer)
+    return loss.detach(), rgb.detach()
+
+
+def resident_backprop_step(renderer, pose, image_loss: Callable, loss_scale=1.0, rank: int = 0, world: int = 1, optimizer=None,
+                           with_classes: bool = False):
+    """The stylisation iteration WITHOUT the deferral: the frame is rendered once, with autograd, its activations stay in HBM,
+    and d loss / d rgb goes back through that one render.
+
+    The reference renders the frame without autograd, takes the image loss's gradient and then re-renders the frame patch by
+    patch with autograd to back-propagate it (trainers/style.py:162-204) because the activations of 762 048 rays do not fit
+    the GPUs it was written for.  Here they do: marched samples, the sample order, the encoded features (128 B per sample) and
+    the composite's sums of a 1008x756 frame are ~10 GB of 288, so nothing is marched, sorted, gathered or composited twice.
+    The gradient is the same sum over the same rays (deterministic march, no perturbation): equal to deferred_backprop_step's
+    up to fp32 summation order (tests).  1008x756 iteration: 38.3-39.4 -> 29.3 ms.
+
+    Same arguments and return value as deferred_backprop_step (no patch_size / patch_graphs).  world > 1: every rank renders
+    (and later back-propagates through) its band of rows; the bands are all-gathered so that every rank evaluates the image loss
+    on the whole frame, as in render_full_frame."""
+    W, H = renderer.intr.size()
+    C = renderer.raymarch_channels
+    y0, y1 = (0, H) if world == 1 else P.shard_bounds(H, rank, world)
+    out = None
+    if y1 > y0:
+        out = renderer.render(pose, None, patch=None if world == 1 else Box2D(0, y0, W, y1 - y0), training=True)
+        part = torch.cat((out['rgb_map'].detach(), out['classes'].detach()), dim=1)
+    else:
+        part = torch.empty(0, C, device=renderer.device)
+    if world == 1:
+        full = part
+    else:
+        sizes = [(P.shard_bounds(H, r, world)[1] - P.shard_bounds(H, r, world)[0]) * W for r in range(world)]
+        chunks = [torch.empty(n, C, device=renderer.device) for n in sizes]
+        if len(set(sizes)) == 1:
+            torch.distributed.all_gather(chunks, part.contiguous())
+        else:
+            _all_gather_ragged(chunks, part)
+        full = torch.cat(chunks, 0)
+    rgb = full[:, :3].reshape(H, W, 3).clone().requires_grad_(True)
+    loss = image_loss(rgb, full[:, 3:].reshape(H, W, C - 3)) if with_classes else image_loss(rgb)
+    (loss * loss_scale).backward()
+    if out is not None:
+        out['rgb_map'].backward(rgb.grad.reshape(-1, 3)[y0 * W:y1 * W])
     if world > 1:
         P.sync_gradients(renderer.model, optimizer=optimizer)
     return loss.detach(), rgb.detach()

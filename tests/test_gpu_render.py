@@ -981,6 +981,15 @@ def test_graphed_patch_backward_equals_eager(O, dev):
         assert rel_l2(g_serial.cpu().numpy(), g_eager.cpu().numpy()) < 1e-5, it
         gt = g_graph[:m.table_elems].view(m.rows, 2, 2)
         assert float(gt[:, 0].abs().max()) == 0.0 and float(gt[:, 1].abs().max()) > 0.0
+    # the whole frame rendered ONCE with autograd (activations resident), no deferral: the same gradient
+    from nerfstyle_amd.stylize import resident_backprop_step
+    pose = torch.tensor(poses[3], device=dev)
+    m.arena.grad.zero_()
+    l_res, rgb_res = resident_backprop_step(r, pose, image_loss, loss_scale=1024.0)
+    g_res = m.arena.grad.clone()
+    l_def, rgb_def = (lambda: (m.arena.grad.zero_(), deferred_backprop_step(r, pose, image_loss, patch_size=200, loss_scale=1024.0))[1])()
+    assert torch.equal(rgb_res, rgb_def) and float(l_res) == float(l_def)
+    assert rel_l2(g_res.cpu().numpy(), g_eager.cpu().numpy()) < 1e-5
     # 6 patches of 4 shapes: one graph per (shape, stream slot) they fell on / per shape
     assert sum(isinstance(v, GraphedPatchBackward) for v in graphs.values()) == 6
     assert sum(isinstance(v, GraphedPatchBackward) for v in serial.values()) == 4

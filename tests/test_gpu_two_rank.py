@@ -96,7 +96,7 @@ from nerfstyle_amd.optim import FusedAdam, LossScaler
 from nerfstyle_amd.renderer import Renderer
 from nerfstyle_amd.scene import load_room_cameras, synthetic_density_grid
 from nerfstyle_amd.style_nerf import StyleTCNerf
-from nerfstyle_amd.stylize import deferred_backprop_step
+from nerfstyle_amd.stylize import deferred_backprop_step, resident_backprop_step
 nc = 5
 model = StyleTCNerf(NetworkConfig(), BBox.from_radius(2.0), nc, enc_dtype=None, use_dir=False)
 with torch.no_grad():
@@ -124,8 +124,12 @@ def image_loss(rgb, classes):
     return torch.mean(wgt * (rgb - tgt) ** 2) + 0.1 * torch.mean((rgb[1:] - rgb[:-1]) ** 2)
 
 pose = torch.tensor(poses[1], device=dev)
-loss, rgb = deferred_backprop_step(r, pose, image_loss, patch_size=64, loss_scale=scaler.scale_tensor(dev), rank=rank, world=world,
-                                   optimizer=opt, with_classes=True)
+if os.environ.get("NSR_STYLE_MODE") == "resident":
+    loss, rgb = resident_backprop_step(r, pose, image_loss, loss_scale=scaler.scale_tensor(dev), rank=rank, world=world,
+                                       optimizer=opt, with_classes=True)
+else:
+    loss, rgb = deferred_backprop_step(r, pose, image_loss, patch_size=64, loss_scale=scaler.scale_tensor(dev), rank=rank, world=world,
+                                       optimizer=opt, with_classes=True)
 grad = (model.arena.grad.detach() / 1024.0).cpu()
 opt.step(scaler=scaler)
 torch.cuda.synchronize()
@@ -227,6 +231,24 @@ def test_two_ranks_stylisation_iteration_equals_one_rank(tmp_path):
     assert torch.equal(ta[:, 0], t1[:, 0]) and torch.equal(a['arena'][n_tab:], one['arena'][n_tab:])
     assert float((ta[:, 1] - t1[:, 1]).abs().max()) <= 0.2 + 1e-6             # Adam step 1: |delta| = lr per touched entry
     assert float(((ta[:, 1] - t1[:, 1]).abs() > 1e-3).float().mean()) < 1e-3
+
+
+def test_resident_stylisation_iteration_on_two_ranks_equals_the_deferred_one(tmp_path):
+    """stylize.resident_backprop_step (the frame rendered ONCE with autograd, activations kept; every rank its band of rows --
+    68 / 67 of 135: the ragged all-gather) at world = 2 against the reference-shaped deferred iteration at world = 1: same
+    frame, same loss, same colour-table gradient up to summation order, replicas identical after the optimiser step."""
+    script = tmp_path / 'child_style.py'
+    script.write_text(CHILD_STYLE)
+    a, b = _run(script, 2, tmp_path, 'r2', extra_env={'NSR_STYLE_MODE': 'resident'})
+    one = _run(script, 1, tmp_path, 'd1')[0]
+    n_tab = 6299960 * 4
+    assert torch.equal(a['rgb'], b['rgb']) and float((a['rgb'] - one['rgb']).abs().max()) < 1e-6
+    assert abs(float(a['loss']) - float(one['loss'])) < 1e-6 * abs(float(one['loss']))
+    ga, gb, g1 = (x['grad'][:n_tab].view(-1, 2, 2) for x in (a, b, one))
+    assert torch.equal(ga[:, 1], gb[:, 1]) and float(ga[:, 0].abs().max()) == 0.0
+    rel = float((ga[:, 1].double() - g1[:, 1].double()).norm() / g1[:, 1].double().norm())
+    assert rel < 1e-5, rel
+    assert torch.equal(a['arena'], b['arena'])
 
 
 def test_bench_self_launches_two_ranks_from_a_plain_invocation(tmp_path):
