@@ -1226,11 +1226,12 @@ int nsr_field_bwd_launch_gout(const FieldBwdArgs &b, int table_dtype, int comput
 // Colour-table-only form of the gradients-out backward: the stylisation stage trains `x_color_embedder` alone (trainers/style.py:25),
 // so no weight gradient is wanted (grad_mlp == NULL) and nothing behind the density output either.  What is left of the chain is
 // the forward recompute of the class and colour nets (for the ReLU masks) and their input gradients -- 60 of the full kernel's
-// ~190 MFMAs, none of its 240 accumulators, so the kernel runs at two waves per SIMD (LDS: the 60 KB weight image) instead of one
+// ~190 MFMAs, none of its 240 accumulators, so the kernel runs at four waves per SIMD (512-thread workgroups around one 60 KB weight image) instead of one
 // (1008x756 stylisation iteration, 24 patches on four streams: 41.1 -> 39.4 ms).  Same helper calls in the same order as the full kernel: the
 // colour gradients are bit-identical to its.  gout's density components are written as zeros (the scatter ignores them).
+constexpr int COLOR_THREADS = 512;       // 8 waves share one 60 KB weight image: two workgroups per CU = four waves per SIMD (90 registers)
 template <int CD>
-__global__ void __launch_bounds__(BWD_THREADS)
+__global__ void __launch_bounds__(COLOR_THREADS)
 k_field_bwd_color(FieldBwdArgs b) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     short *wl = reinterpret_cast<short *>(smem);
@@ -1247,7 +1248,7 @@ k_field_bwd_color(FieldBwdArgs b) {
     const uint32_t tpb = (ntiles + gridDim.x - 1) / gridDim.x;
     const uint32_t t_begin = lb * tpb;
     const uint32_t t_end = min(t_begin + tpb, ntiles);
-    for (uint32_t tile = t_begin + wave; tile < t_end; tile += BWD_THREADS / 64) {
+    for (uint32_t tile = t_begin + wave; tile < t_end; tile += COLOR_THREADS / 64) {
         const uint32_t mpos = tile * 16 + s;
         const bool valid = mpos < Mc;
         const uint32_t m = a.perm[min(mpos, Mc - 1u)];
@@ -1341,10 +1342,10 @@ static int field_bwd_launch_color(const FieldBwdArgs &b, hipStream_t s) {
     }
     // two resident workgroups per CU; >= 8 tiles per wave so that the weight-image build amortises
     const uint32_t ntiles = (b.f.M + 15) / 16;
-    uint32_t nb = (ntiles + 31) / 32;
+    uint32_t nb = (ntiles + 63) / 64;
     if (nb > 512) nb = 512;
     if (nb == 0) nb = 1;
-    hipLaunchKernelGGL((k_field_bwd_color<CD>), dim3(nb), dim3(BWD_THREADS), lds, s, b);
+    hipLaunchKernelGGL((k_field_bwd_color<CD>), dim3(nb), dim3(COLOR_THREADS), lds, s, b);
     return nsr_launch_status();
 }
 
