@@ -20,11 +20,12 @@
 // number of tiles and the kernel indexes its look-back states out of range -- the MEMORY_APERTURE_VIOLATION of round 2.
 // It also made every eager call host-synchronise on the null stream four times.
 //
-// Algorithm: least-significant-digit radix sort of the 30-bit Morton keys, three passes of 10 bits, the classic
+// Algorithm: least-significant-digit radix sort of the Morton keys -- 27 significant bits, see k_order_keys -- in three passes of
+// 9 bits, the classic
 // three-kernel pass (no look-back, no spinning, so no forward-progress assumption):
 //   upsweep    block b counts the digits of its contiguous run of 4096-key tiles        -> spine[digit][block]
 //   spine      one block per digit: exclusive scan over the blocks, digit total         -> spine, totals[digit]
-//   downsweep  block b walks its tiles in order; per tile every wave ranks its 1024 keys 64 at a time (ten ballots give
+//   downsweep  block b walks its tiles in order; per tile every wave ranks its 1024 keys 64 at a time (nine ballots give
 //              a lane the set of lanes with its digit: rank = per-wave LDS counter + lower lanes in the set; one lane of
 //              the set advances the counter -- deterministic, order-preserving), the four waves' counts are prefixed
 //              per digit and scanned over the digits, keys then values go through an LDS tile in sorted order so that a
@@ -43,8 +44,9 @@
 #define SO_IPT 16
 #define SO_TILE (SO_THREADS * SO_IPT)          // 4096 keys
 #define SO_WAVE_ITEMS (64 * SO_IPT)            // 1024 keys per wave and tile
-#define SO_BITS 10
-#define SO_BINS 1024
+#define SO_BITS 9                              // 27 key bits: see k_order_keys
+#define SO_BINS 512
+#define SO_BPT (SO_BINS / SO_THREADS)          // digits per thread in the per-digit loops
 #define SO_MAX_BLOCKS 1024
 #ifndef SO_BLOCKS_TARGET
 #define SO_BLOCKS_TARGET 1024                  // 4 resident blocks per CU
@@ -108,6 +110,13 @@ k_order_keys(OrderArgs a) {
                     const float s = fminf(fmaxf(u * 1024.0f, 0.0f), 1023.0f);     // NaN -> 0
                     q[d] = (uint32_t)s;
                 }
+                // The encoder input of a position inside the bounding box is in [0.5, 1] (BBox.normalize to [0, 1], then the
+                // encoder's (x + 1) / 2): the top bit of every 10-bit coordinate is set, so the order of the 30-bit Morton codes is
+                // the order of the 27-bit codes of the low 9 bits -- three 9-bit digits instead of three 10-bit ones (half the
+                // bins: 8-key runs per tile in the scatter instead of 4, 9 ballots per rank instead of 10).  A position outside
+                // the box (never produced by the march, which clamps) sorts with the box's face.
+#pragma unroll
+                for (int d = 0; d < 3; d++) q[d] = q[d] >= 512u ? q[d] - 512u : 0u;
                 const uint32_t key = order_spread10(q[0]) | (order_spread10(q[1]) << 1) | (order_spread10(q[2]) << 2);
                 a.keys[i] = key;
                 atomicAdd(&hist[key & (SO_BINS - 1)], 1u);
@@ -185,14 +194,14 @@ k_sort_downsweep(SortArgs a) {
     const uint64_t lt_mask = (1ull << lane) - 1ull;
 
     {   // digit starts (scan of the totals) + this block's offset inside each digit
-        uint32_t v[4], s = 0;
+        uint32_t v[SO_BPT], s = 0;
 #pragma unroll
-        for (uint32_t j = 0; j < 4; j++) { v[j] = a.totals[tid * 4 + j]; s += v[j]; }
+        for (uint32_t j = 0; j < SO_BPT; j++) { v[j] = a.totals[tid * SO_BPT + j]; s += v[j]; }
         uint32_t total;
         uint32_t ex = rm_block_exclusive_scan(s, wsum, total);
 #pragma unroll
-        for (uint32_t j = 0; j < 4; j++) {
-            const uint32_t d = tid * 4 + j;
+        for (uint32_t j = 0; j < SO_BPT; j++) {
+            const uint32_t d = tid * SO_BPT + j;
             gbase[d] = ex + a.spine[(size_t)d * a.nb + blockIdx.x];
             ex += v[j];
         }
@@ -247,10 +256,10 @@ k_sort_downsweep(SortArgs a) {
 
         // ---- per digit: prefix over the waves, total; then the scan over the digits ----
         {
-            uint32_t tot[4], s = 0;
+            uint32_t tot[SO_BPT], s = 0;
 #pragma unroll
-            for (uint32_t j = 0; j < 4; j++) {
-                const uint32_t d = tid * 4 + j;
+            for (uint32_t j = 0; j < SO_BPT; j++) {
+                const uint32_t d = tid * SO_BPT + j;
                 uint32_t run = 0;
 #pragma unroll
                 for (uint32_t w = 0; w < SO_THREADS / 64; w++) {
@@ -264,8 +273,8 @@ k_sort_downsweep(SortArgs a) {
             uint32_t total;
             uint32_t ex = rm_block_exclusive_scan(s, wsum, total);    // syncs twice
 #pragma unroll
-            for (uint32_t j = 0; j < 4; j++) {
-                dstart[tid * 4 + j] = ex;
+            for (uint32_t j = 0; j < SO_BPT; j++) {
+                dstart[tid * SO_BPT + j] = ex;
                 ex += tot[j];
             }
         }
@@ -299,8 +308,8 @@ k_sort_downsweep(SortArgs a) {
         for (uint32_t k = 0; k < SO_IPT; k++)
             if (base + k * 64 < n) stage[pos[k]] = val[k];
 #pragma unroll
-        for (uint32_t j = 0; j < 4; j++) {
-            const uint32_t d = tid * 4 + j;
+        for (uint32_t j = 0; j < SO_BPT; j++) {
+            const uint32_t d = tid * SO_BPT + j;
             const uint32_t next = d + 1 < SO_BINS ? dstart[d + 1] : tile_n;
             gbase[d] += next - dstart[d];
         }
