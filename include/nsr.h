@@ -294,7 +294,9 @@ uint64_t nsr_field_backward_workspace_bytes(uint32_t M, int with_perm);
  * order inside a 4^3-finest-cell block), followed by the remaining slots in identity order.  sort_prefix <= M caps the
  * number of leading slots that take part in the sort; the kernels bound themselves by min(m_dev[0], sort_prefix) on the
  * device, so M is the normal value (a smaller one is still correct: the slots past it keep identity order).  The sort is
- * the library's own 3 x 10-bit LSD radix sort: stream-ordered, no host call, capture-safe, deterministic.
+ * the library's own LSD radix sort (3 x 9 bits: the encoder input of a position inside the box is in [0.5, 1], so the top bit
+ * of every coordinate is constant; positions outside the box sort with its faces): stream-ordered, no host call, capture-safe,
+ * deterministic.
  * Consumed by nsr_field_forward / nsr_field_backward (spatial walk, table scatter in spatial order).
  * workspace: nsr_sample_order_workspace_bytes(M) bytes, 256-byte aligned.  bbox_min / bbox_size: HOST float[3]. */
 uint64_t nsr_sample_order_workspace_bytes(uint32_t M);
