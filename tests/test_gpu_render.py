@@ -1084,3 +1084,26 @@ def test_begin_train_on_a_side_stream_equals_plain_render(O, dev):
         assert torch.equal(r._last_counter, want_cnt)
         out['rgb_map'].sum().backward()                                      # the backward walks the side stream's permutation
         del ctx, out, want
+    # two contexts rewritten in place in turn (no allocation per step), with the renderer's own step bookkeeping running:
+    # the occupancy schedule's step counter and the count ring advance exactly as on the allocating path
+    r.update_occ = True
+    r.local_step = 1                                                         # (not a multiple of update_iter: no update is due)
+    stage = [None, None]
+    pix = torch.randperm(intr.w * intr.h, device=dev, generator=g)[:30000]
+    for it in range(4):
+        pose = torch.tensor(poses[it + 4], device=dev)
+        step0 = r.local_step
+        want = r.render(pose, None, training=True, pix_subset=pix)
+        want_cnt = r._last_counter.clone()
+        assert r.local_step == step0 + 1
+        ev = torch.cuda.Event()
+        ev.record()
+        stage[it % 2] = r.begin_train_on(side, pose, pix, after=ev, into=stage[it % 2])
+        assert r.local_step == step0 + 2
+        out = r.finish_train(stage[it % 2])
+        for k in ('rgb_map', 'trans_map', 'classes'):
+            assert torch.equal(out[k], want[k]), (it, k)
+        assert torch.equal(r._last_counter, want_cnt)
+        assert torch.equal(r.step_counter[(step0 + 1) % r.step_counter.shape[0]], want_cnt)
+        out['rgb_map'].sum().backward()
+    r.update_occ = False
