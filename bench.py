@@ -724,7 +724,10 @@ def run_style(args, dev, rank, world):
             'style_backprop': args.style_backprop,
             'rays_per_step': W * H, 'patches': n_patches, 'max_steps': rcfg.max_steps, 'num_classes': nc,
             'table_dtype': args.table_dtype, 'mfma_dtype': args.compute_dtype,
-            'parallelism': 'patches + pass-1 pixel rows sharded x{}, packed colour-table gradient all-reduce'.format(world),
+            'parallelism': ('bands of pixel rows sharded x{} (rendered with autograd and back-propagated by their rank; the image loss is '
+                            'evaluated on the all-gathered frame), packed colour-table gradient all-reduce'.format(world)
+                            if args.style_backprop == 'resident' else
+                            'patches + pass-1 pixel rows sharded x{}, packed colour-table gradient all-reduce'.format(world)),
             'final_loss': float(loss) , 'matching': crit.style_loss.matching,
         },
         'kernel_ms_per_step': {k: round(v[1] / args.steps, 4) for k, v in sorted(prof.items())},
