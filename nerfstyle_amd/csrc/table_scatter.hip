@@ -11,8 +11,8 @@
 // group of finest-level cells for the reference's 16-level grid).  Consecutive samples -- of MANY rays -- share a block,
 // and a block touches only a handful of cells on every level: at most ceil(res_l / 1024) + 1 per axis.  So the wave
 // keeps, per level, a small LATTICE of corner gradients in LDS anchored at the cell of the block's origin (ceil(res / 1024)
-// + 2 corners per axis: for the reference's LLFF grid -- 16 levels, resolutions 16 .. 2047 -- 4^3 on the three finest levels
-// and 3^3 below, 543 float4 = 8.5 KB per wave; grids up to 6^3 per level and 1024 slots in all are accepted).  Lane = (level l = lane >> 2,
+// + 2 corners per axis: for the reference's LLFF grid -- 16 levels, resolutions 16 .. 4096 -- 5^3 on the two finest levels,
+// 4^3 on the next two and 3^3 below, 702 float4 = 11 KB per wave; grids up to 6^3 per level and 960 slots in all are accepted).  Lane = (level l = lane >> 2,
 // y/z corner pair p = lane & 3) walks the samples in order and adds its two x corners' contributions with a plain LDS
 // read-modify-write: within a step the 64 lanes touch 128 different slots and steps are sequential, so no atomics are
 // needed; the lattice is addressed by cell coordinates, so nothing is hashed per sample.  When the walk enters a new
