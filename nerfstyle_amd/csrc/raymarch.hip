@@ -1048,13 +1048,9 @@ int nsr_march_rays_train(const float *rays_o, const float *rays_d, const float *
     // the ~30 waves per CU its 32 registers allow, more partially written lines are open than the L2 holds.  60 KB of (unused)
     // dynamic LDS per workgroup keeps two workgroups per CU: 1.12-1.20 -> 0.87-1.09 ms on the bench frame (box to box); the
     // closed-form step of k_march_emit_mask takes another ~15 us at that occupancy, nothing at full occupancy.
-    static const int emit_lds = [] { const char *e = getenv("NSR_MARCH_EMIT_LDS"); return e ? atoi(e) : 61440; }();
+    static const int emit_lds = [] { const char *e = getenv("NSR_MARCH_EMIT_LDS"); const int v = e ? atoi(e) : 61440; return v < 0 ? 0 : (v > 64000 ? 64000 : v); }();
     static const int closed_env = [] { const char *e = getenv("NSR_MARCH_EMIT_CLOSED"); return e ? atoi(e) : 1; }();
     if (use_mask) {
-        if (emit_lds > 0) {
-            static bool attr = false;
-            if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_march_emit_mask), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64); attr = true; }
-        }
         hipLaunchKernelGGL(k_march_emit_mask, dim3(nblocks), dim3(RM_BLOCK), (size_t)emit_lds, s, rays_o, rays_d, bound, dt_gamma, max_steps, N, C,
                            H, M, nears, noises, counts, block_sums, mask, xyzs, dirs, deltas, rays, closed_env);
     }
