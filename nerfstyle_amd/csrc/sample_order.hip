@@ -23,7 +23,7 @@
 // Algorithm: least-significant-digit radix sort of the Morton keys -- 27 significant bits, see k_order_keys -- in three passes of
 // 9 bits, the classic
 // three-kernel pass (no look-back, no spinning, so no forward-progress assumption):
-//   upsweep    block b counts the digits of its contiguous run of 4096-key tiles        -> spine[digit][block]
+//   upsweep    block b counts the digits of its contiguous run of 8192-key tiles        -> spine[digit][block]
 //   spine      one block per digit: exclusive scan over the blocks, digit total         -> spine, totals[digit]
 //   downsweep  block b walks its tiles in order; per tile every wave ranks its 1024 keys 64 at a time (nine ballots give
 //              a lane the set of lanes with its digit: rank = per-wave LDS counter + lower lanes in the set; one lane of
@@ -40,16 +40,16 @@
 #include "nsr_common.h"
 #include "rm_util.h"
 
-#define SO_THREADS 256
+#define SO_THREADS 512
 #define SO_IPT 16
-#define SO_TILE (SO_THREADS * SO_IPT)          // 4096 keys
+#define SO_TILE (SO_THREADS * SO_IPT)          // 8192 keys
 #define SO_WAVE_ITEMS (64 * SO_IPT)            // 1024 keys per wave and tile
 #define SO_BITS 9                              // 27 key bits: see k_order_keys
 #define SO_BINS 512
 #define SO_BPT (SO_BINS / SO_THREADS)          // digits per thread in the per-digit loops
 #define SO_MAX_BLOCKS 1024
 #ifndef SO_BLOCKS_TARGET
-#define SO_BLOCKS_TARGET 1024                  // 4 resident blocks per CU
+#define SO_BLOCKS_TARGET 768                   // 3 resident blocks per CU (52 KB of LDS each)
 #endif
 
 struct OrderArgs {
